@@ -1,0 +1,334 @@
+// circuit_host.h -- host-side marshalling of the reference's circuit types into constraint rows.
+//
+// Restates, in C++ over flat arrays (all paths into /root/reference):
+//   affineCircuitToAffineMap  src/Circuit/Affine.hs:90-105
+//   evalAffineCircuit         src/Circuit/Affine.hs:73-86
+//   evalGate/evalArithCircuit src/Circuit/Arithmetic.hs:106-145,221-235
+//   validArithCircuit         src/Circuit/Arithmetic.hs:158-185
+//   generateRoots (row count) src/Circuit/Arithmetic.hs:194-216
+//   gateToGenQAP              src/QAP.hs:366-474   (row contents: SURVEY.md Appendix A.2)
+//   qapSetToMap numbering     src/QAP.hs:605-620
+#pragma once
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/acx.h"
+#include "host_field.h"
+
+namespace acx {
+
+struct SparseRow {
+    std::vector<uint32_t> col;
+    std::vector<H256> val;  // Montgomery (host radix)
+};
+
+struct HostCsr {
+    std::vector<uint32_t> rowptr{0};
+    std::vector<uint32_t> col;
+    std::vector<H256> val;  // canonical
+    void push_row(const HostField& hf, const std::map<uint64_t, H256>& row) {
+        for (const auto& kv : row) {
+            if (kv.second.is_zero()) continue;  // explicit zeros of the reference are numerically void
+            col.push_back((uint32_t)kv.first);
+            val.push_back(hf.from_mont(kv.second));
+        }
+        rowptr.push_back((uint32_t)col.size());
+    }
+};
+
+class HostCircuit {
+public:
+    HostField hf;
+    uint64_t n_gates = 0;
+    std::vector<uint8_t> kind;
+    std::vector<uint64_t> tok_ofs;
+    std::vector<uint8_t> tok_op;
+    std::vector<uint32_t> tok_arg;
+    std::vector<H256> scalars;  // Montgomery
+    std::vector<acx_wire> aff_wires;
+    std::vector<uint64_t> wire_ofs;
+    std::vector<acx_wire> wires;
+    uint64_t n_in = 0, n_mid = 0, n_out = 0;
+
+    uint64_t m() const { return 1 + n_in + n_mid + n_out; }
+    uint64_t flat(const acx_wire& w) const {
+        switch (w.kind) {
+            case ACX_WIRE_INPUT: return 1 + w.index;
+            case ACX_WIRE_INTERMEDIATE: return 1 + n_in + w.index;
+            default: return 1 + n_in + n_mid + w.index;
+        }
+    }
+    uint64_t rows_of_gate(uint64_t g) const {
+        switch (kind[g]) {
+            case ACX_GATE_MUL: return 1;
+            case ACX_GATE_EQUAL: return 2;
+            default: return wire_ofs[g + 1] - wire_ofs[g];  // 1 + #outputs
+        }
+    }
+    uint64_t n_rows() const {
+        uint64_t n = 0;
+        for (uint64_t g = 0; g < n_gates; ++g) n += rows_of_gate(g);
+        return n;
+    }
+
+    // Copies + validates the marshalled list; returns ACX_OK or an error with msg set.
+    int init(const acx_gate_list* gl, std::string& msg) {
+        if (!gl) { msg = "null gate list"; return ACX_ERR_INVALID_ARG; }
+        n_gates = gl->n_gates;
+        if (n_gates && (!gl->kind || !gl->tok_ofs || !gl->wire_ofs)) { msg = "null gate arrays"; return ACX_ERR_INVALID_ARG; }
+        kind.assign(gl->kind, gl->kind + n_gates);
+        tok_ofs.assign(gl->tok_ofs, gl->tok_ofs + 2 * n_gates + 1);
+        wire_ofs.assign(gl->wire_ofs, gl->wire_ofs + n_gates + 1);
+        if (n_gates == 0) { tok_ofs = {0}; wire_ofs = {0}; }
+        const uint64_t n_tok = tok_ofs.back(), n_w = wire_ofs.back();
+        for (size_t i = 0; i + 1 < tok_ofs.size(); ++i)
+            if (tok_ofs[i] > tok_ofs[i + 1]) { msg = "tok_ofs not monotone"; return ACX_ERR_BAD_CIRCUIT; }
+        for (size_t i = 0; i + 1 < wire_ofs.size(); ++i)
+            if (wire_ofs[i] > wire_ofs[i + 1]) { msg = "wire_ofs not monotone"; return ACX_ERR_BAD_CIRCUIT; }
+        if (n_tok) { tok_op.assign(gl->tok_op, gl->tok_op + n_tok); tok_arg.assign(gl->tok_arg, gl->tok_arg + n_tok); }
+        if (n_w) wires.assign(gl->wires, gl->wires + n_w);
+        if (gl->n_aff_wires) aff_wires.assign(gl->aff_wires, gl->aff_wires + gl->n_aff_wires);
+        scalars.resize(gl->n_scalars);
+        for (uint64_t i = 0; i < gl->n_scalars; ++i) {
+            H256 c;
+            std::memcpy(c.l, gl->scalars[i].b, 32);
+            if (!hf.is_canonical(c)) { msg = "scalar >= p"; return ACX_ERR_NONCANONICAL; }
+            scalars[i] = hf.to_mont(c);
+        }
+        auto bump = [&](const acx_wire& w) -> bool {
+            if (w.kind > ACX_WIRE_OUTPUT || w.index >= 0x7fffffffu) return false;
+            uint64_t& d = w.kind == ACX_WIRE_INPUT ? n_in : (w.kind == ACX_WIRE_INTERMEDIATE ? n_mid : n_out);
+            d = std::max<uint64_t>(d, (uint64_t)w.index + 1);
+            return true;
+        };
+        for (const auto& w : wires) if (!bump(w)) { msg = "bad wire"; return ACX_ERR_BAD_CIRCUIT; }
+        for (const auto& w : aff_wires) if (!bump(w)) { msg = "bad wire"; return ACX_ERR_BAD_CIRCUIT; }
+        for (uint64_t g = 0; g < n_gates; ++g) {
+            const uint64_t nw = wire_ofs[g + 1] - wire_ofs[g];
+            const bool has_tok = tok_ofs[2 * g + 2] > tok_ofs[2 * g];
+            if (kind[g] == ACX_GATE_MUL) {
+                if (nw != 1) { msg = "Mul gate needs exactly one wire"; return ACX_ERR_BAD_CIRCUIT; }
+                for (int side = 0; side < 2; ++side) {
+                    uint64_t pos = tok_ofs[2 * g + side];
+                    if (!check_tree(pos, tok_ofs[2 * g + side + 1], gl) || pos != tok_ofs[2 * g + side + 1]) {
+                        msg = "malformed affine token stream"; return ACX_ERR_BAD_CIRCUIT;
+                    }
+                }
+            } else if (kind[g] == ACX_GATE_EQUAL) {
+                if (nw != 3 || has_tok) { msg = "Equal gate needs three wires"; return ACX_ERR_BAD_CIRCUIT; }
+            } else if (kind[g] == ACX_GATE_SPLIT) {
+                if (nw < 1 || has_tok) { msg = "Split gate needs an input wire"; return ACX_ERR_BAD_CIRCUIT; }
+            } else { msg = "unknown gate kind"; return ACX_ERR_BAD_CIRCUIT; }
+        }
+        if (m() >= 0xffffffffull) { msg = "too many wires"; return ACX_ERR_TOO_LARGE; }
+        return ACX_OK;
+    }
+
+    // affineCircuitToAffineMap on the token range starting at pos (advanced past the sub-tree).
+    void affine_map(uint64_t& pos, H256& cst, std::map<uint64_t, H256>& vec) const {
+        const uint8_t op = tok_op[pos];
+        const uint32_t arg = tok_arg[pos];
+        ++pos;
+        switch (op) {
+            case ACX_AFF_VAR:
+                cst = hf.zero();
+                vec.clear();
+                vec[flat(aff_wires[arg])] = hf.one();
+                break;
+            case ACX_AFF_CONST:
+                cst = scalars[arg];
+                vec.clear();
+                break;
+            case ACX_AFF_SCALARMUL: {
+                affine_map(pos, cst, vec);
+                cst = hf.mul(scalars[arg], cst);
+                for (auto& kv : vec) kv.second = hf.mul(scalars[arg], kv.second);
+                break;
+            }
+            default: {  // ADD: Map.unionWith (+)
+                H256 cr;
+                std::map<uint64_t, H256> vr;
+                affine_map(pos, cst, vec);
+                affine_map(pos, cr, vr);
+                cst = hf.add(cst, cr);
+                for (const auto& kv : vr) {
+                    auto it = vec.find(kv.first);
+                    if (it == vec.end()) vec.emplace(kv.first, kv.second);
+                    else it->second = hf.add(it->second, kv.second);
+                }
+            }
+        }
+    }
+
+    // evalAffineCircuit: failed lookups are 0.
+    H256 affine_eval(uint64_t& pos, const std::vector<H256>& w, const std::vector<uint8_t>& assigned) const {
+        const uint8_t op = tok_op[pos];
+        const uint32_t arg = tok_arg[pos];
+        ++pos;
+        switch (op) {
+            case ACX_AFF_VAR: {
+                const uint64_t k = flat(aff_wires[arg]);
+                return assigned[k] ? w[k] : hf.zero();
+            }
+            case ACX_AFF_CONST: return scalars[arg];
+            case ACX_AFF_SCALARMUL: return hf.mul(affine_eval(pos, w, assigned), scalars[arg]);
+            default: {
+                const H256 l = affine_eval(pos, w, assigned);
+                const H256 r = affine_eval(pos, w, assigned);
+                return hf.add(l, r);
+            }
+        }
+    }
+
+    // gateToGenQAP over every gate, rows in gate order.
+    void build_rows(HostCsr& A, HostCsr& B, HostCsr& C) const {
+        const H256 one = hf.one(), minus_one = hf.neg(hf.one()), zero = hf.zero();
+        for (uint64_t g = 0; g < n_gates; ++g) {
+            const acx_wire* gw = &wires[wire_ofs[g]];
+            if (kind[g] == ACX_GATE_MUL) {
+                std::map<uint64_t, H256> l, r, o;
+                H256 lc, rc;
+                uint64_t pos = tok_ofs[2 * g];
+                affine_map(pos, lc, l);
+                pos = tok_ofs[2 * g + 1];
+                affine_map(pos, rc, r);
+                l[0] = lc;  // constantQapSet (root, leftInputConst): a Var can never name column 0
+                r[0] = rc;
+                o[flat(gw[0])] = one;
+                A.push_row(hf, l); B.push_row(hf, r); C.push_row(hf, o);
+            } else if (kind[g] == ACX_GATE_EQUAL) {
+                const uint64_t i = flat(gw[0]), mg = flat(gw[1]), out = flat(gw[2]);
+                auto set3 = [&](H256 vi, H256 vm, H256 vo, H256 cst) {
+                    std::map<uint64_t, H256> row;
+                    row[0] = cst;
+                    row[i] = vi; row[mg] = vm; row[out] = vo;  // updateAtWires: later entries overwrite
+                    return row;
+                };
+                A.push_row(hf, set3(one, zero, zero, zero));       // row0: i * m = out
+                B.push_row(hf, set3(zero, one, zero, zero));
+                C.push_row(hf, set3(zero, zero, one, zero));
+                A.push_row(hf, set3(zero, zero, minus_one, one));  // row1: (1 - out) * i = 0
+                B.push_row(hf, set3(one, zero, zero, zero));
+                C.push_row(hf, set3(zero, zero, zero, zero));
+            } else {
+                const uint64_t n_outs = wire_ofs[g + 1] - wire_ofs[g] - 1;
+                const uint64_t inp = flat(gw[0]);
+                std::map<uint64_t, H256> a0, b0, c0;
+                a0[0] = zero; a0[inp] = zero;
+                H256 pw = one;  // 2^j
+                for (uint64_t j = 0; j < n_outs; ++j) {
+                    a0[flat(gw[1 + j])] = pw;
+                    pw = hf.add(pw, pw);
+                }
+                b0[0] = one; b0[inp] = zero;
+                c0[0] = zero; c0[inp] = one;
+                A.push_row(hf, a0); B.push_row(hf, b0); C.push_row(hf, c0);
+                for (uint64_t j = 0; j < n_outs; ++j) {  // bit * (1 - bit) = 0
+                    const uint64_t o = flat(gw[1 + j]);
+                    std::map<uint64_t, H256> a, b, c;
+                    a[0] = zero; a[o] = one;
+                    b[0] = one; b[o] = minus_one;
+                    A.push_row(hf, a); B.push_row(hf, b); C.push_row(hf, c);
+                }
+            }
+        }
+    }
+
+    // generateAssignment.  inputs canonical.  Returns ACX_OK / ACX_ERR_UNDEFINED_WIRE.
+    int eval(const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs, std::vector<H256>& w,
+             std::vector<uint8_t>& assigned, std::string& msg) const {
+        w.assign(m(), hf.zero());
+        assigned.assign(m(), 0);
+        w[0] = hf.one();
+        assigned[0] = 1;
+        for (uint64_t i = 0; i < n_inputs && i < n_in; ++i) {
+            if (present && !present[i]) continue;
+            H256 c;
+            std::memcpy(c.l, inputs[i].b, 32);
+            if (!hf.is_canonical(c)) { msg = "input >= p"; return ACX_ERR_NONCANONICAL; }
+            w[1 + i] = hf.to_mont(c);
+            assigned[1 + i] = 1;
+        }
+        for (uint64_t g = 0; g < n_gates; ++g) {
+            const acx_wire* gw = &wires[wire_ofs[g]];
+            if (kind[g] == ACX_GATE_MUL) {
+                uint64_t pos = tok_ofs[2 * g];
+                const H256 l = affine_eval(pos, w, assigned);
+                pos = tok_ofs[2 * g + 1];
+                const H256 r = affine_eval(pos, w, assigned);
+                const uint64_t o = flat(gw[0]);
+                w[o] = hf.mul(l, r);
+                assigned[o] = 1;
+            } else if (kind[g] == ACX_GATE_EQUAL) {
+                const uint64_t i = flat(gw[0]), mg = flat(gw[1]), o = flat(gw[2]);
+                if (!assigned[i]) { msg = "evalGate: the impossible happened (Equal input unassigned)"; return ACX_ERR_UNDEFINED_WIRE; }
+                const bool z = w[i].is_zero();
+                const H256 inv = z ? hf.zero() : hf.inv(w[i]);
+                w[mg] = inv; assigned[mg] = 1;                       // updateVar m mid
+                w[o] = z ? hf.zero() : hf.one(); assigned[o] = 1;    // then updateVar outputWire res
+            } else {
+                const uint64_t i = flat(gw[0]);
+                if (!assigned[i]) { msg = "evalGate: the impossible happened (Split input unassigned)"; return ACX_ERR_UNDEFINED_WIRE; }
+                const H256 c = hf.from_mont(w[i]);
+                const uint64_t n_outs = wire_ofs[g + 1] - wire_ofs[g] - 1;
+                for (uint64_t j = 0; j < n_outs; ++j) {
+                    const bool bit = j < 256 && ((c.l[j / 64] >> (j % 64)) & 1);
+                    const uint64_t o = flat(gw[1 + j]);
+                    w[o] = bit ? hf.one() : hf.zero();
+                    assigned[o] = 1;
+                }
+            }
+        }
+        return ACX_OK;
+    }
+
+    bool valid() const {
+        std::vector<uint8_t> defined(n_mid, 0);
+        bool res = true;
+        for (uint64_t g = 0; g < n_gates; ++g) {
+            const acx_wire* gw = &wires[wire_ofs[g]];
+            const uint64_t nw = wire_ofs[g + 1] - wire_ofs[g];
+            auto valid_wire = [&](const acx_wire& w) {
+                if (w.kind == ACX_WIRE_INPUT) return true;
+                if (w.kind == ACX_WIRE_OUTPUT) return false;
+                return defined[w.index] != 0;
+            };
+            bool ok = true;
+            if (kind[g] == ACX_GATE_MUL) {
+                ok = gw[0].kind != ACX_WIRE_INPUT;
+                for (uint64_t t = tok_ofs[2 * g]; t < tok_ofs[2 * g + 2]; ++t)
+                    if (tok_op[t] == ACX_AFF_VAR) ok = ok && valid_wire(aff_wires[tok_arg[t]]);
+            } else if (kind[g] == ACX_GATE_EQUAL) {
+                ok = gw[2].kind != ACX_WIRE_INPUT && valid_wire(gw[0]);  // outputWires = [eqOutput]
+            } else {
+                for (uint64_t j = 1; j < nw; ++j) ok = ok && gw[j].kind != ACX_WIRE_INPUT;
+                ok = ok && valid_wire(gw[0]);
+            }
+            res = res && ok;
+            // outputWires gate ++ definedWires
+            if (kind[g] == ACX_GATE_MUL) { if (gw[0].kind == ACX_WIRE_INTERMEDIATE) defined[gw[0].index] = 1; }
+            else if (kind[g] == ACX_GATE_EQUAL) { if (gw[2].kind == ACX_WIRE_INTERMEDIATE) defined[gw[2].index] = 1; }
+            else for (uint64_t j = 1; j < nw; ++j) if (gw[j].kind == ACX_WIRE_INTERMEDIATE) defined[gw[j].index] = 1;
+        }
+        return res;
+    }
+
+private:
+    bool check_tree(uint64_t& pos, uint64_t end, const acx_gate_list* gl) const {
+        if (pos >= end) return false;
+        const uint8_t op = tok_op[pos];
+        const uint32_t arg = tok_arg[pos];
+        ++pos;
+        switch (op) {
+            case ACX_AFF_VAR: return arg < gl->n_aff_wires;
+            case ACX_AFF_CONST: return arg < gl->n_scalars;
+            case ACX_AFF_SCALARMUL: return arg < gl->n_scalars && check_tree(pos, end, gl);
+            case ACX_AFF_ADD: return check_tree(pos, end, gl) && check_tree(pos, end, gl);
+            default: return false;
+        }
+    }
+};
+
+}  // namespace acx

@@ -1,0 +1,816 @@
+// engine.hip -- libacx.so: contexts, device-resident constraint systems, kernel orchestration
+// and the C ABI of include/acx.h.  One context = one GPU (one process per GPU in multi-GPU
+// jobs; the collectives live in the host layer above this library, over RCCL).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/acx.h"
+#include "circuit_host.h"
+#include "host_field.h"
+#include "kernels.cuh"
+
+using namespace acx;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? ACX_ERR_OOM : ACX_ERR_HIP,                \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+#define ACX_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != ACX_OK) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ handles
+struct acx_ctx {
+    int field = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    HostField hf;
+    std::mutex mu;
+    std::map<std::pair<uint32_t, int>, uint4*> twiddles;  // (log_n, inverse) -> omega^j table
+    unsigned long long* d_result = nullptr;                // {n_bad, first_bad}
+    uint32_t* d_err = nullptr;
+    int n_cu = 256;
+};
+
+struct DevMatrix {
+    u32* ptr = nullptr;   // rowptr (CSR) or colptr (CSC)
+    u32* idx = nullptr;   // col (CSR) or row (CSC)
+    uint4* val = nullptr; // dev format
+    uint64_t nnz = 0;
+};
+
+struct acx_r1cs {
+    acx_ctx* ctx = nullptr;
+    uint64_t n = 0, m = 0;
+    uint32_t log_n = 0;
+    DevMatrix M[3];
+    DevMatrix T[3];        // CSC, built lazily for acx_qap_columns
+    bool has_csc = false;
+    uint4* d_w = nullptr;  // witness staging, m elements
+};
+
+struct acx_circuit {
+    HostCircuit hc;
+    HostCsr rows[3];     // gateToGenQAP rows in gate order, built once
+};
+
+namespace {
+
+struct DevBuf {  // RAII scratch
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+        return ACX_OK;
+    }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+inline int grid_for(const acx_ctx* c, uint64_t work_items, int per_cu = 8) {
+    const uint64_t blocks = (work_items + kBlock - 1) / kBlock;
+    const uint64_t cap = (uint64_t)c->n_cu * per_cu;
+    return (int)std::max<uint64_t>(1, std::min(blocks, cap));
+}
+
+inline FeArg dev_arg(const HostField& hf, const H256& mont) {
+    FeArg a;
+    hf.to_dev_limbs(mont, a.l);
+    return a;
+}
+
+inline uint32_t ceil_log2(uint64_t n) {
+    uint32_t k = 0;
+    while ((1ull << k) < n) ++k;
+    return k;
+}
+
+// ---- field dispatch ---------------------------------------------------------------------
+#define DISPATCH_FIELD(ctx, CALL)                         \
+    do {                                                  \
+        if ((ctx)->field == ACX_FIELD_BN254_FR) { using F = Bn254Fr; CALL; }        \
+        else { using F = Bls12381Fr; CALL; }              \
+    } while (0)
+
+int launch_convert(acx_ctx* c, bool to_dev, const void* in, void* out, uint64_t count, uint32_t* d_err) {
+    if (count == 0) return ACX_OK;
+    const int grid = grid_for(c, count);
+    DISPATCH_FIELD(c, {
+        if (to_dev) hipLaunchKernelGGL((k_convert<F, true>), dim3(grid), dim3(kBlock), 0, c->stream,
+                                       (const uint4*)in, (uint4*)out, count, d_err);
+        else hipLaunchKernelGGL((k_convert<F, false>), dim3(grid), dim3(kBlock), 0, c->stream,
+                                (const uint4*)in, (uint4*)out, count, d_err);
+    });
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+// Upload canonical host elements and convert to dev format in place; checks canonicity.
+int upload_elements(acx_ctx* c, const acx_fr* host, uint64_t count, uint4* d_out) {
+    if (count == 0) return ACX_OK;
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, 4, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_out, host, count * 32, hipMemcpyHostToDevice, c->stream));
+    ACX_TRY(launch_convert(c, true, d_out, d_out, count, c->d_err));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err) return fail(ACX_ERR_NONCANONICAL, "element >= p");
+    return ACX_OK;
+}
+
+int download_elements(acx_ctx* c, const uint4* d_in, uint64_t count, acx_fr* host, uint4* d_scratch) {
+    if (count == 0) return ACX_OK;
+    ACX_TRY(launch_convert(c, false, d_in, d_scratch, count, nullptr));
+    HIP_TRY(hipMemcpyAsync(host, d_scratch, count * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ACX_OK;
+}
+
+// omega_N^j table (j < N/2), cached per (log_n, inverse).  Caller holds ctx->mu.
+int get_twiddles(acx_ctx* c, uint32_t log_n, int inverse, uint4** out) {
+    auto key = std::make_pair(log_n, inverse);
+    auto it = c->twiddles.find(key);
+    if (it != c->twiddles.end()) { *out = it->second; return ACX_OK; }
+    const uint64_t count = log_n ? (1ull << (log_n - 1)) : 1;
+    uint4* tw = nullptr;
+    HIP_TRY(hipMalloc((void**)&tw, count * 32));
+    H256 w = c->hf.root_of_unity((int)log_n);
+    if (inverse) w = c->hf.inv(w);
+    const FeArg base = dev_arg(c->hf, w);
+    const int grid = grid_for(c, count);
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid), dim3(kBlock), 0, c->stream, tw, count, base));
+    HIP_TRY(hipGetLastError());
+    c->twiddles[key] = tw;
+    *out = tw;
+    return ACX_OK;
+}
+
+// In-place batched NTT on dev-format data.  Caller holds ctx->mu.
+//   forward: X[k] = sum_i x[i] (shift * omega^k)^i      inverse: undoes it.
+int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inverse, const H256* shift_mont) {
+    if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
+    if (batch == 0) return ACX_OK;
+    const uint64_t n = 1ull << log_n;
+    const HostField& hf = c->hf;
+    if (!inverse && shift_mont) {
+        const FeArg one = dev_arg(hf, hf.one()), g = dev_arg(hf, *shift_mont);
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_scale_powers<F>), dim3(grid_for(c, n * batch)), dim3(kBlock), 0,
+                                             c->stream, d, log_n, batch, one, g, 1));
+    }
+    if (log_n > 0) {
+        uint4* tw = nullptr;
+        ACX_TRY(get_twiddles(c, log_n, inverse, &tw));
+        hipLaunchKernelGGL(k_bitrev_permute, dim3(grid_for(c, n * batch)), dim3(kBlock), 0, c->stream, d, log_n, batch);
+        for (uint32_t lh = 0; lh < log_n; ++lh) {
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_stage<F>), dim3(grid_for(c, (n >> 1) * batch)), dim3(kBlock), 0,
+                                                 c->stream, d, (const uint4*)tw, log_n, lh, batch));
+        }
+    }
+    if (inverse) {
+        const H256 ninv = hf.inv(hf.from_u64(n));
+        const FeArg s = dev_arg(hf, ninv);
+        const H256 ginv = shift_mont ? hf.inv(*shift_mont) : hf.one();
+        const FeArg g = dev_arg(hf, ginv);
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_scale_powers<F>), dim3(grid_for(c, n * batch)), dim3(kBlock), 0,
+                                             c->stream, d, log_n, batch, s, g, shift_mont ? 1 : 0));
+    }
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned long long* d_result,
+                    uint4* d_res, uint4* d_dots, uint64_t dots_stride) {
+    acx_ctx* c = r->ctx;
+    if (r->n == 0) return ACX_OK;
+    CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val},
+        C{r->M[2].ptr, r->M[2].idx, r->M[2].val};
+    const int grid = grid_for(c, r->n, 16);
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_residual<F>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C, d_w,
+                                         r->n, row_offset, d_result, d_res, d_dots, dots_stride));
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int read_h256(const acx_fr* f, const HostField& hf, H256& mont) {
+    H256 c;
+    std::memcpy(c.l, f->b, 32);
+    if (!hf.is_canonical(c)) return fail(ACX_ERR_NONCANONICAL, "element >= p");
+    mont = hf.to_mont(c);
+    return ACX_OK;
+}
+
+void write_h256(acx_fr* f, const HostField& hf, const H256& mont) {
+    const H256 c = hf.from_mont(mont);
+    std::memcpy(f->b, c.l, 32);
+}
+
+// Sort + merge duplicate columns of one host CSR row set (only rows that need it).
+int normalise_csr(const HostField& hf, uint64_t n, uint64_t m, const acx_csr* in, std::vector<uint32_t>& rowptr,
+                  std::vector<uint32_t>& col, std::vector<acx_fr>& val) {
+    if (!in || !in->rowptr) return fail(ACX_ERR_INVALID_ARG, "null CSR");
+    const uint64_t nnz = in->rowptr[n];
+    if (in->rowptr[0] != 0) return fail(ACX_ERR_INVALID_ARG, "rowptr[0] != 0");
+    if (nnz && (!in->col || !in->val)) return fail(ACX_ERR_INVALID_ARG, "null CSR arrays");
+    rowptr.assign(1, 0);
+    rowptr.reserve(n + 1);
+    col.reserve(nnz);
+    val.reserve(nnz);
+    std::vector<std::pair<uint32_t, uint64_t>> tmp;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t e0 = in->rowptr[i], e1 = in->rowptr[i + 1];
+        if (e1 < e0) return fail(ACX_ERR_INVALID_ARG, "rowptr not monotone");
+        bool sorted = true;
+        for (uint32_t e = e0; e < e1; ++e) {
+            if (in->col[e] >= m) return fail(ACX_ERR_INVALID_ARG, "column index >= m");
+            if (e > e0 && in->col[e] <= in->col[e - 1]) sorted = false;
+        }
+        if (sorted) {
+            col.insert(col.end(), in->col + e0, in->col + e1);
+            val.insert(val.end(), in->val + e0, in->val + e1);
+        } else {
+            tmp.clear();
+            for (uint32_t e = e0; e < e1; ++e) tmp.emplace_back(in->col[e], e);
+            std::stable_sort(tmp.begin(), tmp.end(), [](auto& a, auto& b) { return a.first < b.first; });
+            for (size_t k = 0; k < tmp.size();) {
+                H256 acc;
+                ACX_TRY(read_h256(&in->val[tmp[k].second], hf, acc));
+                size_t j = k + 1;
+                for (; j < tmp.size() && tmp[j].first == tmp[k].first; ++j) {
+                    H256 t;
+                    ACX_TRY(read_h256(&in->val[tmp[j].second], hf, t));
+                    acc = hf.add(acc, t);
+                }
+                col.push_back(tmp[k].first);
+                acx_fr f;
+                write_h256(&f, hf, acc);
+                val.push_back(f);
+                k = j;
+            }
+        }
+        rowptr.push_back((uint32_t)col.size());
+    }
+    return ACX_OK;
+}
+
+int upload_matrix(acx_ctx* c, const std::vector<uint32_t>& ptr, const std::vector<uint32_t>& idx,
+                  const acx_fr* val, bool convert, DevMatrix& out) {
+    out.nnz = idx.size();
+    HIP_TRY(hipMalloc((void**)&out.ptr, ptr.size() * 4));
+    HIP_TRY(hipMalloc((void**)&out.idx, std::max<size_t>(idx.size(), 1) * 4));
+    HIP_TRY(hipMalloc((void**)&out.val, std::max<size_t>(idx.size(), 1) * 32));
+    HIP_TRY(hipMemcpyAsync(out.ptr, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!idx.empty()) HIP_TRY(hipMemcpyAsync(out.idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (convert) {
+        ACX_TRY(upload_elements(c, val, idx.size(), out.val));
+    } else {
+        if (!idx.empty()) HIP_TRY(hipMemcpyAsync(out.val, val, idx.size() * 32, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ACX_OK;
+}
+
+void free_matrix(DevMatrix& mtx) {
+    if (mtx.ptr) (void)hipFree(mtx.ptr);
+    if (mtx.idx) (void)hipFree(mtx.idx);
+    if (mtx.val) (void)hipFree(mtx.val);
+    mtx = DevMatrix{};
+}
+
+int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3], acx_r1cs** out) {
+    if (!ctx || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (m == 0 || m >= 0xffffffffull || n >= 0xffffffffull) return fail(ACX_ERR_TOO_LARGE, "n or m out of range");
+    const uint32_t log_n = ceil_log2(std::max<uint64_t>(n, 1));
+    if ((int)log_n > ctx->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "n exceeds 2^two_adicity");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    acx_r1cs* r = new (std::nothrow) acx_r1cs();
+    if (!r) return fail(ACX_ERR_OOM, "host allocation failed");
+    r->ctx = ctx; r->n = n; r->m = m; r->log_n = log_n;
+    int rc = ACX_OK;
+    for (int k = 0; k < 3 && rc == ACX_OK; ++k) {
+        std::vector<uint32_t> rowptr, col;
+        std::vector<acx_fr> val;
+        rc = normalise_csr(ctx->hf, n, m, mats[k], rowptr, col, val);
+        if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, col, val.data(), true, r->M[k]);
+    }
+    if (rc == ACX_OK) {
+        hipError_t e = hipMalloc((void**)&r->d_w, m * 32);
+        if (e != hipSuccess) rc = fail(ACX_ERR_OOM, "witness buffer allocation failed");
+    }
+    if (rc != ACX_OK) {
+        for (int k = 0; k < 3; ++k) free_matrix(r->M[k]);
+        if (r->d_w) (void)hipFree(r->d_w);
+        delete r;
+        return rc;
+    }
+    *out = r;
+    return ACX_OK;
+}
+
+// Build the CSC copies (device) from the device CSR.  Caller holds ctx->mu.
+int ensure_csc(acx_r1cs* r) {
+    if (r->has_csc) return ACX_OK;
+    acx_ctx* c = r->ctx;
+    for (int k = 0; k < 3; ++k) {
+        const uint64_t nnz = r->M[k].nnz;
+        std::vector<uint32_t> rowptr(r->n + 1), col(nnz);
+        std::vector<acx_fr> val(nnz), tval(nnz);
+        HIP_TRY(hipMemcpy(rowptr.data(), r->M[k].ptr, (r->n + 1) * 4, hipMemcpyDeviceToHost));
+        if (nnz) {
+            HIP_TRY(hipMemcpy(col.data(), r->M[k].idx, nnz * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(val.data(), r->M[k].val, nnz * 32, hipMemcpyDeviceToHost));  // raw dev format
+        }
+        std::vector<uint32_t> colptr(r->m + 1, 0), rowidx(nnz);
+        for (uint64_t e = 0; e < nnz; ++e) ++colptr[col[e] + 1];
+        for (uint64_t j = 0; j < r->m; ++j) colptr[j + 1] += colptr[j];
+        std::vector<uint32_t> cursor(colptr.begin(), colptr.end() - 1);
+        for (uint64_t i = 0; i < r->n; ++i)
+            for (uint32_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+                const uint32_t dst = cursor[col[e]]++;
+                rowidx[dst] = (uint32_t)i;
+                tval[dst] = val[e];
+            }
+        ACX_TRY(upload_matrix(c, colptr, rowidx, tval.data(), false, r->T[k]));
+    }
+    r->has_csc = true;
+    return ACX_OK;
+}
+
+}  // namespace
+
+// ==================================================================================== C ABI
+extern "C" {
+
+const char* acx_strerror(int status) {
+    switch (status) {
+        case ACX_OK: return "ok";
+        case ACX_ERR_INVALID_ARG: return "invalid argument";
+        case ACX_ERR_NONCANONICAL: return "field element is not canonical (>= p)";
+        case ACX_ERR_NO_DEVICE: return "no usable HIP device";
+        case ACX_ERR_HIP: return "HIP runtime error";
+        case ACX_ERR_ROOT_COUNT: return "gateToGenQAP: wrong number of roots supplied";
+        case ACX_ERR_UNDEFINED_WIRE: return "evalGate: the impossible happened (undefined wire)";
+        case ACX_ERR_DUPLICATE_ROOT: return "duplicate root";
+        case ACX_ERR_TOO_LARGE: return "size exceeds supported range";
+        case ACX_ERR_OOM: return "out of memory";
+        case ACX_ERR_BAD_CIRCUIT: return "malformed marshalled circuit";
+        case ACX_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+const char* acx_last_error(void) { return g_last_error.c_str(); }
+uint32_t acx_version(void) { return ACX_VERSION; }
+
+int acx_ctx_create(int field, int device_id, acx_ctx** out) {
+    if (!out) return fail(ACX_ERR_INVALID_ARG, "null out pointer");
+    if (field != ACX_FIELD_BN254_FR && field != ACX_FIELD_BLS12_381_FR) return fail(ACX_ERR_INVALID_ARG, "unknown field");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(ACX_ERR_NO_DEVICE, "no HIP device visible (libacx has no CPU fallback)");
+    if (device_id < 0 || device_id >= count) return fail(ACX_ERR_NO_DEVICE, "device id out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(ACX_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libacx is built for gfx950 only");
+    HIP_TRY(hipSetDevice(device_id));
+    acx_ctx* c = new (std::nothrow) acx_ctx();
+    if (!c) return fail(ACX_ERR_OOM, "host allocation failed");
+    c->field = field;
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->hf = field == ACX_FIELD_BN254_FR ? HostField::make<Bn254Fr>() : HostField::make<Bls12381Fr>();
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&c->d_result, 16) != hipSuccess || hipMalloc((void**)&c->d_err, 4) != hipSuccess) {
+        acx_ctx_destroy(c);
+        return fail(ACX_ERR_HIP, "context resource creation failed");
+    }
+    *out = c;
+    return ACX_OK;
+}
+
+void acx_ctx_destroy(acx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->twiddles) (void)hipFree(kv.second);
+    if (c->d_result) (void)hipFree(c->d_result);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int acx_ctx_set_root(acx_ctx* c, uint32_t two_adicity, const acx_fr* omega) {
+    if (!c || !omega || two_adicity == 0 || two_adicity > 64) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    H256 w;
+    ACX_TRY(read_h256(omega, c->hf, w));
+    // must have exact order 2^two_adicity: w^(2^(s-1)) == -1
+    H256 t = w;
+    for (uint32_t i = 0; i + 1 < two_adicity; ++i) t = c->hf.mul(t, t);
+    if (t != c->hf.neg(c->hf.one())) return fail(ACX_ERR_INVALID_ARG, "omega is not a primitive 2^s-th root of unity");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& kv : c->twiddles) (void)hipFree(kv.second);
+    c->twiddles.clear();
+    c->hf.set_omega_max(w, (int)two_adicity);
+    return ACX_OK;
+}
+
+int acx_ctx_root_of_unity(acx_ctx* c, uint32_t k, acx_fr* out) {
+    if (!c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if ((int)k > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "getRootOfUnity: exponent out of range");
+    write_h256(out, c->hf, c->hf.root_of_unity((int)k));
+    return ACX_OK;
+}
+
+int acx_ctx_sync(acx_ctx* c) {
+    if (!c) return fail(ACX_ERR_INVALID_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ACX_OK;
+}
+
+void* acx_ctx_stream(acx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------- circuit
+int acx_circuit_create(int field, const acx_gate_list* gates, acx_circuit** out) {
+    if (!gates || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (field != ACX_FIELD_BN254_FR && field != ACX_FIELD_BLS12_381_FR) return fail(ACX_ERR_INVALID_ARG, "unknown field");
+    acx_circuit* c = new (std::nothrow) acx_circuit();
+    if (!c) return fail(ACX_ERR_OOM, "host allocation failed");
+    c->hc.hf = field == ACX_FIELD_BN254_FR ? HostField::make<Bn254Fr>() : HostField::make<Bls12381Fr>();
+    std::string msg;
+    const int rc = c->hc.init(gates, msg);
+    if (rc != ACX_OK) { delete c; return fail(rc, msg); }
+    c->hc.build_rows(c->rows[0], c->rows[1], c->rows[2]);
+    *out = c;
+    return ACX_OK;
+}
+
+void acx_circuit_destroy(acx_circuit* c) { delete c; }
+
+int acx_circuit_dims(const acx_circuit* c, uint64_t* n_rows, uint64_t* m_wires, uint64_t* n_inputs,
+                     uint64_t* n_intermediates, uint64_t* n_outputs) {
+    if (!c) return fail(ACX_ERR_INVALID_ARG, "null circuit");
+    if (n_rows) *n_rows = c->hc.n_rows();
+    if (m_wires) *m_wires = c->hc.m();
+    if (n_inputs) *n_inputs = c->hc.n_in;
+    if (n_intermediates) *n_intermediates = c->hc.n_mid;
+    if (n_outputs) *n_outputs = c->hc.n_out;
+    return ACX_OK;
+}
+
+int acx_circuit_rows_per_gate(const acx_circuit* c, uint32_t* out) {
+    if (!c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    for (uint64_t g = 0; g < c->hc.n_gates; ++g) out[g] = (uint32_t)c->hc.rows_of_gate(g);
+    return ACX_OK;
+}
+
+int acx_circuit_valid(const acx_circuit* c, int* valid) {
+    if (!c || !valid) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    *valid = c->hc.valid() ? 1 : 0;
+    return ACX_OK;
+}
+
+int acx_circuit_eval(const acx_circuit* c, const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs,
+                     acx_fr* witness, uint8_t* assigned) {
+    if (!c || !witness || (n_inputs && !inputs)) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    std::vector<H256> w;
+    std::vector<uint8_t> as;
+    std::string msg;
+    const int rc = c->hc.eval(inputs, present, n_inputs, w, as, msg);
+    if (rc != ACX_OK) return fail(rc, msg);
+    for (uint64_t k = 0; k < w.size(); ++k) write_h256(&witness[k], c->hc.hf, w[k]);
+    if (assigned) std::memcpy(assigned, as.data(), as.size());
+    return ACX_OK;
+}
+
+// rows in ascending-root order (`Map.elems`, src/QAP.hs:521-523); empty order = identity
+static int root_order(const HostCircuit& hc, const acx_fr* roots, uint64_t n_roots, std::vector<uint64_t>& order) {
+    const uint64_t n = hc.n_rows();
+    order.clear();
+    if (!roots) return ACX_OK;
+    if (n_roots != n) return fail(ACX_ERR_ROOT_COUNT, "gateToGenQAP: wrong number of roots supplied");
+    std::vector<H256> rv(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        std::memcpy(rv[i].l, roots[i].b, 32);
+        if (!hc.hf.is_canonical(rv[i])) return fail(ACX_ERR_NONCANONICAL, "root >= p");
+    }
+    order.resize(n);
+    for (uint64_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return h256_cmp(rv[a], rv[b]) < 0; });
+    bool identity = true;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (i && rv[order[i]] == rv[order[i - 1]]) return fail(ACX_ERR_DUPLICATE_ROOT, "roots must be distinct");
+        identity = identity && order[i] == i;
+    }
+    if (identity) order.clear();
+    return ACX_OK;
+}
+
+static void permute_rows(const HostCsr& src, const std::vector<uint64_t>& order, HostCsr& dst) {
+    dst = HostCsr();
+    for (uint64_t s : order) {
+        for (uint32_t e = src.rowptr[s]; e < src.rowptr[s + 1]; ++e) {
+            dst.col.push_back(src.col[e]);
+            dst.val.push_back(src.val[e]);
+        }
+        dst.rowptr.push_back((uint32_t)dst.col.size());
+    }
+}
+
+int acx_circuit_nnz(const acx_circuit* c, uint64_t nnz[3]) {
+    if (!c || !nnz) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    for (int k = 0; k < 3; ++k) nnz[k] = c->rows[k].col.size();
+    return ACX_OK;
+}
+
+int acx_circuit_rows(const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, int matrix, uint32_t* rowptr,
+                     uint32_t* col, acx_fr* val) {
+    if (!c || matrix < 0 || matrix > 2 || !rowptr) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    std::vector<uint64_t> order;
+    ACX_TRY(root_order(c->hc, roots, n_roots, order));
+    HostCsr perm;
+    const HostCsr* src = &c->rows[matrix];
+    if (!order.empty()) { permute_rows(*src, order, perm); src = &perm; }
+    std::memcpy(rowptr, src->rowptr.data(), src->rowptr.size() * 4);
+    if (col && !src->col.empty()) std::memcpy(col, src->col.data(), src->col.size() * 4);
+    if (val && !src->val.empty()) std::memcpy(val, src->val.data(), src->val.size() * 32);
+    return ACX_OK;
+}
+
+int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_r1cs** out) {
+    if (!ctx || !c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    const HostCircuit& hc = c->hc;
+    std::vector<uint64_t> order;
+    ACX_TRY(root_order(hc, roots, n_roots, order));
+    acx_csr views[3];
+    HostCsr P[3];
+    for (int k = 0; k < 3; ++k) {
+        const HostCsr* src = &c->rows[k];
+        if (!order.empty()) { permute_rows(*src, order, P[k]); src = &P[k]; }
+        views[k] = acx_csr{src->rowptr.data(), src->col.data(), reinterpret_cast<const acx_fr*>(src->val.data())};
+    }
+    const acx_csr* mats[3] = {&views[0], &views[1], &views[2]};
+    return r1cs_from_host(ctx, hc.n_rows(), hc.m(), mats, out);
+}
+
+// ---------------------------------------------------------------------------------- R1CS
+int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C,
+                  acx_r1cs** out) {
+    const acx_csr* mats[3] = {A, B, C};
+    return r1cs_from_host(ctx, n, m, mats, out);
+}
+
+void acx_r1cs_destroy(acx_r1cs* r) {
+    if (!r) return;
+    {
+        std::lock_guard<std::mutex> lock(r->ctx->mu);
+        (void)hipSetDevice(r->ctx->device);
+        (void)hipStreamSynchronize(r->ctx->stream);
+        for (int k = 0; k < 3; ++k) { free_matrix(r->M[k]); free_matrix(r->T[k]); }
+        if (r->d_w) (void)hipFree(r->d_w);
+    }
+    delete r;
+}
+
+int acx_r1cs_dims(const acx_r1cs* r, uint64_t* n, uint64_t* m, uint32_t* log_n, uint64_t nnz[3]) {
+    if (!r) return fail(ACX_ERR_INVALID_ARG, "null r1cs");
+    if (n) *n = r->n;
+    if (m) *m = r->m;
+    if (log_n) *log_n = r->log_n;
+    if (nnz) for (int k = 0; k < 3; ++k) nnz[k] = r->M[k].nnz;
+    return ACX_OK;
+}
+
+int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* col, acx_fr* val) {
+    if (!r || matrix < 0 || matrix > 2 || !rowptr) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    acx_ctx* c = r->ctx;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const DevMatrix& M = r->M[matrix];
+    HIP_TRY(hipMemcpy(rowptr, M.ptr, (r->n + 1) * 4, hipMemcpyDeviceToHost));
+    if (M.nnz && col) HIP_TRY(hipMemcpy(col, M.idx, M.nnz * 4, hipMemcpyDeviceToHost));
+    if (M.nnz && val) {
+        DevBuf tmp;
+        ACX_TRY(tmp.alloc(M.nnz * 32));
+        ACX_TRY(download_elements(c, M.val, M.nnz, val, tmp.as<uint4>()));
+    }
+    return ACX_OK;
+}
+
+static int verify_common(acx_r1cs* r, const acx_fr* witness, uint64_t* n_bad, uint64_t* first_bad, uint4* d_res,
+                         uint4* d_dots, uint64_t dots_stride) {
+    acx_ctx* c = r->ctx;
+    ACX_TRY(upload_elements(c, witness, r->m, r->d_w));
+    const unsigned long long init[2] = {0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(c->d_result, init, 16, hipMemcpyHostToDevice, c->stream));
+    ACX_TRY(launch_residual(r, r->d_w, 0, c->d_result, d_res, d_dots, dots_stride));
+    unsigned long long res[2];
+    HIP_TRY(hipMemcpyAsync(res, c->d_result, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_bad) *n_bad = res[0];
+    if (first_bad) *first_bad = res[1];
+    return ACX_OK;
+}
+
+int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
+    if (!r || !witness || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(r->ctx->mu);
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    uint64_t bad = 0, first = ~0ull;
+    ACX_TRY(verify_common(r, witness, &bad, &first, nullptr, nullptr, 0));
+    *ok = bad == 0;
+    if (n_bad) *n_bad = bad;
+    if (first_bad) *first_bad = first;
+    return ACX_OK;
+}
+
+int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out) {
+    if (!r || !witness || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    acx_ctx* c = r->ctx;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf res;
+    ACX_TRY(res.alloc(r->n * 32));
+    ACX_TRY(verify_common(r, witness, nullptr, nullptr, res.as<uint4>(), nullptr, 0));
+    return download_elements(c, res.as<uint4>(), r->n, out, res.as<uint4>());
+}
+
+int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok) {
+    if (!r || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    acx_ctx* c = r->ctx;
+    const HostField& hf = c->hf;
+    if ((int)r->log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t N = 1ull << r->log_n;
+    DevBuf dots, keep;
+    ACX_TRY(dots.alloc(3 * N * 32));
+    uint4* d = dots.as<uint4>();
+    HIP_TRY(hipMemsetAsync(d, 0, 3 * N * 32, c->stream));  // rows n..N-1 are the zero padding
+    uint64_t bad = 0;
+    ACX_TRY(verify_common(r, witness, &bad, nullptr, nullptr, d, N));
+    *ok = bad == 0;
+    // evaluations on <omega> -> coefficients of L0, R0, O0
+    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr));
+    H256 dl[3];
+    bool zk = false;
+    if (delta) {
+        for (int k = 0; k < 3; ++k) { ACX_TRY(read_h256(&delta[k], hf, dl[k])); zk = zk || !dl[k].is_zero(); }
+    }
+    if (zk) {
+        ACX_TRY(keep.alloc(2 * N * 32));
+        HIP_TRY(hipMemcpyAsync(keep.p, d, 2 * N * 32, hipMemcpyDeviceToDevice, c->stream));
+    }
+    // coset evaluations, shift = multiplicative generator g (g^N != 1)
+    const H256 g = hf.generator();
+    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, &g));
+    const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, c->stream, d,
+                                         (const uint4*)(d + 2 * N), (const uint4*)(d + 4 * N), N, dev_arg(hf, zinv)));
+    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 1, 1, &g));
+    if (zk) {
+        // (L0+d1 T)(R0+d2 T) - (O0+d3 T) = T * (h0 + d1 R0 + d2 L0 + d1 d2 T - d3),  T = x^N - 1
+        const uint4* L0 = keep.as<uint4>();
+        const uint4* R0 = L0 + 2 * N;
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy2<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, c->stream, d, R0, L0, N,
+                                             dev_arg(hf, dl[0]), dev_arg(hf, dl[1])));
+    }
+    HIP_TRY(hipGetLastError());
+    ACX_TRY(download_elements(c, d, N, out_h, d + 2 * N));
+    std::memset(out_h[N].b, 0, 32);
+    if (zk) {
+        const H256 d12 = hf.mul(dl[0], dl[1]);
+        H256 h0;
+        ACX_TRY(read_h256(&out_h[0], hf, h0));
+        h0 = hf.sub(hf.sub(h0, d12), dl[2]);
+        write_h256(&out_h[0], hf, h0);
+        write_h256(&out_h[N], hf, d12);
+    }
+    uint64_t len = N + 1;
+    static const uint8_t zero32[32] = {0};
+    while (len > 0 && std::memcmp(out_h[len - 1].b, zero32, 32) == 0) --len;
+    *h_len = len;
+    return ACX_OK;
+}
+
+int acx_qap_columns(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out,
+                    uint64_t* out_len) {
+    if (!r || matrix < 0 || matrix > 2 || !out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
+    acx_ctx* c = r->ctx;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    ACX_TRY(ensure_csc(r));
+    const uint64_t N = 1ull << r->log_n;
+    // stream wire batches: bounded device scratch (<= ~2 GiB per batch)
+    const uint64_t max_batch = std::max<uint64_t>(1, (1ull << 31) / (N * 32));
+    DevBuf buf, tmp;
+    const uint64_t chunk = std::min(max_batch, std::max<uint64_t>(wire_count, 1));
+    ACX_TRY(buf.alloc(chunk * N * 32));
+    ACX_TRY(tmp.alloc(chunk * N * 32));
+    const DevMatrix& T = r->T[matrix];
+    static const uint8_t zero32[32] = {0};
+    for (uint64_t w0 = 0; w0 < wire_count; w0 += chunk) {
+        const uint64_t cnt = std::min(chunk, wire_count - w0);
+        HIP_TRY(hipMemsetAsync(buf.p, 0, cnt * N * 32, c->stream));
+        if (T.nnz) {
+            hipLaunchKernelGGL(k_scatter_columns, dim3(grid_for(c, T.nnz)), dim3(kBlock), 0, c->stream,
+                               (const u32*)T.ptr, (const u32*)T.idx, (const uint4*)T.val, wire_begin + w0, cnt,
+                               r->log_n, buf.as<uint4>());
+        }
+        ACX_TRY(ntt_dev_locked(c, buf.as<uint4>(), r->log_n, cnt, 1, nullptr));
+        ACX_TRY(download_elements(c, buf.as<uint4>(), cnt * N, out + w0 * N, tmp.as<uint4>()));
+        if (out_len) {
+            for (uint64_t w = 0; w < cnt; ++w) {
+                uint64_t len = N;
+                const acx_fr* col = out + (w0 + w) * N;
+                while (len > 0 && std::memcmp(col[len - 1].b, zero32, 32) == 0) --len;
+                out_len[w0 + w] = len;
+            }
+        }
+    }
+    return ACX_OK;
+}
+
+// ---------------------------------------------------------------------------------- NTT
+int acx_ntt(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift, const acx_fr* in,
+            acx_fr* out) {
+    if (!c || !in || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    H256 sh;
+    if (shift) {
+        ACX_TRY(read_h256(shift, c->hf, sh));
+        if (sh.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift must be nonzero");
+    }
+    const uint64_t total = batch << log_n;
+    if (total == 0) return ACX_OK;
+    DevBuf buf, tmp;
+    ACX_TRY(buf.alloc(total * 32));
+    ACX_TRY(tmp.alloc(total * 32));
+    ACX_TRY(upload_elements(c, in, total, buf.as<uint4>()));
+    ACX_TRY(ntt_dev_locked(c, buf.as<uint4>(), log_n, batch, inverse, shift ? &sh : nullptr));
+    return download_elements(c, buf.as<uint4>(), total, out, tmp.as<uint4>());
+}
+
+// ---------------------------------------------------------------------------------- device API
+int acx_dev_from_canonical(acx_ctx* c, uint64_t count, const void* d_in, void* d_out, uint32_t* d_err) {
+    if (!c || !d_in || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    return launch_convert(c, true, d_in, d_out, count, d_err);
+}
+
+int acx_dev_to_canonical(acx_ctx* c, uint64_t count, const void* d_in, void* d_out) {
+    if (!c || !d_in || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    return launch_convert(c, false, d_in, d_out, count, nullptr);
+}
+
+int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset, uint64_t* d_result,
+                        void* d_residuals, void* d_dots) {
+    if (!r || !d_witness || !d_result) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(r->ctx->mu);
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    return launch_residual(r, (const uint4*)d_witness, row_offset, (unsigned long long*)d_result,
+                           (uint4*)d_residuals, (uint4*)d_dots, 1ull << r->log_n);
+}
+
+int acx_ntt_dev(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift, void* d_data) {
+    if (!c || !d_data) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    H256 sh;
+    if (shift) {
+        ACX_TRY(read_h256(shift, c->hf, sh));
+        if (sh.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift must be nonzero");
+    }
+    return ntt_dev_locked(c, (uint4*)d_data, log_n, batch, inverse, shift ? &sh : nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+// fr.cuh -- 256-bit prime-field arithmetic for gfx950 (CDNA4) device code.
+//
+// Replaces the arithmetic of galois-field-1.0.2 `Prime p` (third party; call sites
+// /root/reference/src/QAP.hs:52,87-90,450 and src/Circuit/Arithmetic.hs:131,143) on the device.
+//
+// Representation, chosen from measured gfx950 issue rates (tools/microbench/valu_rates.hip,
+// profiles/r01_valu_rates.txt): v_mad_u64_u32 issues at the SAME rate as v_addc_co_u32
+// (4 cycles per wave64 instruction), so carry handling -- not multiplies -- dominates a
+// 8 x 32-bit-limb Montgomery product (136 mads + >=128 carry ops).  With 9 limbs of 29 bits a
+// column of 18 limb products (< 2^58 each) fits a 64-bit accumulator with no carry tracking:
+// one Montgomery product is 162 v_mad_u64_u32 + 9 v_mul_lo_u32 + 17 v_lshrrev_b64 + 17 v_and
+// and hipcc emits exactly that from plain C++ (no inline asm needed).
+//
+//   * In registers: Fe = 9 limbs, radix 2^29, Montgomery radix R = 2^261.
+//     "Lazy" invariant: limbs < 2^29 (top limb unbounded by the mask), value in [0, 2p).
+//     mul() accepts values < 4p with limbs < 2^30 and returns a lazy value without any
+//     conditional subtraction (a*b/R + p < 2p because 16p/R <= 1/4).
+//   * In memory ("dev" format): the lazy value packed into 8 x u32 little-endian (2p < 2^256).
+//   * At the ABI: canonical [0,p), same packing, plain (non-Montgomery).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "field_consts.h"
+
+namespace acx {
+
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i32 = int32_t;
+
+constexpr int kLimbs = 9;
+constexpr int kLimbBits = 29;
+constexpr u32 kLimbMask = (1u << kLimbBits) - 1;
+
+struct Fe {
+    u32 l[kLimbs];
+};
+
+// Host-prepared element passed by value as a kernel argument (already in limb form).
+struct FeArg {
+    u32 l[kLimbs];
+};
+
+__device__ __forceinline__ Fe fe_from_arg(const FeArg& a) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < kLimbs; ++i) r.l[i] = a.l[i];
+    return r;
+}
+
+__device__ __forceinline__ Fe fe_zero() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < kLimbs; ++i) r.l[i] = 0;
+    return r;
+}
+
+template <class F>
+__device__ __forceinline__ Fe fe_one_mont() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < kLimbs; ++i) r.l[i] = F::R1[i];
+    return r;
+}
+
+// ---- packing: 8 x u32 words <-> 9 x 29-bit limbs -------------------------------------------
+__device__ __forceinline__ Fe fe_unpack(const u32 w[8]) {
+    Fe r;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        const int bit = kLimbBits * k, wi = bit >> 5, off = bit & 31;
+        u64 pair = w[wi];
+        if (wi + 1 < 8) pair |= (u64)w[wi + 1] << 32;
+        r.l[k] = (u32)(pair >> off) & kLimbMask;
+    }
+    return r;
+}
+
+// requires normalized limbs (each < 2^29) and value < 2^256
+__device__ __forceinline__ void fe_pack(const Fe& a, u32 w[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int bit = 32 * j, k0 = bit / kLimbBits, o = bit - kLimbBits * k0;
+        u32 v = a.l[k0] >> o;
+        if (k0 + 1 < kLimbs) v |= a.l[k0 + 1] << (kLimbBits - o);
+        if (k0 + 2 < kLimbs && 2 * kLimbBits - o < 32) v |= a.l[k0 + 2] << (2 * kLimbBits - o);
+        w[j] = v;
+    }
+}
+
+__device__ __forceinline__ Fe fe_load(const uint4* __restrict__ p) {
+    const uint4 lo = p[0], hi = p[1];
+    const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return fe_unpack(w);
+}
+
+__device__ __forceinline__ void fe_store(uint4* __restrict__ p, const Fe& a) {
+    u32 w[8];
+    fe_pack(a, w);
+    p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// ---- carries --------------------------------------------------------------------------------
+// Sequential carry propagation; limbs may be up to 2^32-1 on entry.
+__device__ __forceinline__ void fe_carry(Fe& a) {
+    u32 c = 0;
+#pragma unroll
+    for (int k = 0; k < kLimbs - 1; ++k) {
+        const u32 t = a.l[k] + c;
+        a.l[k] = t & kLimbMask;
+        c = t >> kLimbBits;
+    }
+    a.l[kLimbs - 1] += c;
+}
+
+// a - M if a >= M else a;   a normalized, M a compile-time limb constant.
+template <const u32 (&M)[kLimbs]>
+__device__ __forceinline__ Fe fe_cond_sub(const Fe& a) {
+    Fe d;
+    i32 c = 0;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        const i32 t = (i32)a.l[k] - (i32)M[k] + c;
+        d.l[k] = (k < kLimbs - 1) ? ((u32)t & kLimbMask) : (u32)t;
+        c = t >> kLimbBits;  // arithmetic shift: borrow = -1
+    }
+    const bool neg = c < 0;  // a < M
+    Fe r;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) r.l[k] = neg ? a.l[k] : d.l[k];
+    return r;
+}
+
+// ---- ring operations on lazy values -----------------------------------------------------------
+template <class F>
+__device__ __forceinline__ Fe fe_add(const Fe& a, const Fe& b) {
+    Fe s;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) s.l[k] = a.l[k] + b.l[k];
+    fe_carry(s);
+    return fe_cond_sub<F::P2>(s);
+}
+
+template <class F>
+__device__ __forceinline__ Fe fe_sub(const Fe& a, const Fe& b) {
+    Fe s;
+    i32 c = 0;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        const i32 t = (i32)a.l[k] + (i32)F::P2[k] - (i32)b.l[k] + c;
+        s.l[k] = (k < kLimbs - 1) ? ((u32)t & kLimbMask) : (u32)t;
+        c = t >> kLimbBits;
+    }
+    return fe_cond_sub<F::P2>(s);
+}
+
+// Montgomery product a*b/R mod p, finely integrated product scanning.  a, b: limbs < 2^30,
+// values < 4p.  Result lazy (normalized, < 2p).
+template <class F>
+__device__ __forceinline__ Fe fe_mul(const Fe& a, const Fe& b) {
+    u64 acc = 0;
+    u32 m[kLimbs];
+    Fe r;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (u64)m[i] * F::P[k - i];
+        m[k] = ((u32)acc * F::N0) & kLimbMask;
+        acc += (u64)m[k] * F::P[0];
+        acc >>= kLimbBits;
+    }
+#pragma unroll
+    for (int k = kLimbs; k < 2 * kLimbs - 1; ++k) {
+#pragma unroll
+        for (int i = k - kLimbs + 1; i < kLimbs; ++i) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - kLimbs + 1; i < kLimbs; ++i) acc += (u64)m[i] * F::P[k - i];
+        r.l[k - kLimbs] = (u32)acc & kLimbMask;
+        acc >>= kLimbBits;
+    }
+    r.l[kLimbs - 1] = (u32)acc;
+    return r;
+}
+
+// lazy [0,2p) -> canonical residue [0,p) of the same Montgomery value
+template <class F>
+__device__ __forceinline__ Fe fe_reduce(const Fe& a) {
+    return fe_cond_sub<F::P>(a);
+}
+
+// value == 0 mod p, for a lazy value (0 or p)
+template <class F>
+__device__ __forceinline__ bool fe_is_zero(const Fe& a) {
+    u32 z = 0, e = 0;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        z |= a.l[k];
+        e |= a.l[k] ^ F::P[k];
+    }
+    return z == 0 || e == 0;
+}
+
+template <class F>
+__device__ __forceinline__ Fe fe_to_mont(const Fe& canonical) {
+    Fe r2;
+#pragma unroll
+    for (int i = 0; i < kLimbs; ++i) r2.l[i] = F::R2[i];
+    return fe_mul<F>(canonical, r2);
+}
+
+// Montgomery lazy value -> canonical plain integer in [0,p)
+template <class F>
+__device__ __forceinline__ Fe fe_from_mont(const Fe& a) {
+    Fe one = fe_zero();
+    one.l[0] = 1;
+    return fe_reduce<F>(fe_mul<F>(a, one));
+}
+
+// canonical check on a plain unpacked value: a < p
+template <class F>
+__device__ __forceinline__ bool fe_lt_p(const Fe& a) {
+    i32 c = 0;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        const i32 t = (i32)a.l[k] - (i32)F::P[k] + c;
+        c = t >> kLimbBits;
+    }
+    return c < 0;
+}
+
+// a^e for a 64-bit exponent (square and multiply, LSB first)
+template <class F>
+__device__ __forceinline__ Fe fe_pow(Fe base, u64 e) {
+    Fe acc = fe_one_mont<F>();
+    while (e) {
+        if (e & 1) acc = fe_mul<F>(acc, base);
+        base = fe_mul<F>(base, base);
+        e >>= 1;
+    }
+    return acc;
+}
+
+}  // namespace acx

@@ -1,0 +1,204 @@
+// kernels.cuh -- gfx950 kernels of the R1CS / QAP hot path.  All new code: the reference
+// (pure Haskell) has no kernels; each kernel names the reference computation it performs.
+#pragma once
+#include "fr.cuh"
+
+namespace acx {
+
+constexpr int kBlock = 256;
+
+// Device CSR view (values in dev format: 2 x uint4 per entry).
+struct CsrDev {
+    const u32* rowptr;
+    const u32* col;
+    const uint4* val;
+};
+
+// ---------------------------------------------------------------------------------------------
+// K7: canonical <-> dev (lazy Montgomery) conversion at the ABI edge.
+// to_dev validates canonicity (galois-field keeps residues canonical; a host that passes >= p
+// gets ACX_ERR_NONCANONICAL): *err is set to 1 if any element >= p.
+template <class F, bool TO_DEV>
+__global__ __launch_bounds__(kBlock) void k_convert(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                   u64 count, u32* __restrict__ err) {
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < count; i += (u64)gridDim.x * kBlock) {
+        Fe x = fe_load(in + 2 * i);
+        if (TO_DEV) {
+            if (err != nullptr && !fe_lt_p<F>(x)) atomicOr(err, 1u);
+            fe_store(out + 2 * i, fe_to_mont<F>(x));
+        } else {
+            fe_store(out + 2 * i, fe_from_mont<F>(x));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: R1CS residual check = `verifyAssignment` (/root/reference/src/QAP.hs:276-327) in the
+// evaluation domain: r_i = <A_i,w> * <B_i,w> - <C_i,w> for every constraint row i.
+// One row per lane; a row's entries are contiguous in the CSR value stream.
+template <class F>
+__device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restrict__ w, u64 row) {
+    Fe acc = fe_zero();
+    const u32 e0 = M.rowptr[row], e1 = M.rowptr[row + 1];
+    for (u32 e = e0; e < e1; ++e) {
+        const Fe v = fe_load(M.val + 2 * (u64)e);
+        const Fe x = fe_load(w + 2 * (u64)M.col[e]);
+        acc = fe_add<F>(acc, fe_mul<F>(v, x));
+    }
+    return acc;
+}
+
+// result[0] += number of violated rows; result[1] = min(result[1], first violated global row).
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_r1cs_residual(CsrDev A, CsrDev B, CsrDev C,
+                                                         const uint4* __restrict__ w, u64 n, u64 row_offset,
+                                                         unsigned long long* __restrict__ result,
+                                                         uint4* __restrict__ residuals,
+                                                         uint4* __restrict__ dots, u64 dots_stride) {
+    __shared__ unsigned long long s_bad, s_first;
+    if (threadIdx.x == 0) { s_bad = 0; s_first = ~0ull; }
+    __syncthreads();
+    unsigned long long my_bad = 0, my_first = ~0ull;
+    for (u64 base = (u64)blockIdx.x * kBlock; base < n; base += (u64)gridDim.x * kBlock) {
+        const u64 row = base + threadIdx.x;
+        if (row < n) {
+            const Fe a = csr_row_dot<F>(A, w, row);
+            const Fe b = csr_row_dot<F>(B, w, row);
+            const Fe c = csr_row_dot<F>(C, w, row);
+            const Fe r = fe_sub<F>(fe_mul<F>(a, b), c);
+            if (!fe_is_zero<F>(r)) {
+                ++my_bad;
+                if (row + row_offset < my_first) my_first = row + row_offset;
+            }
+            if (residuals != nullptr) fe_store(residuals + 2 * row, r);
+            if (dots != nullptr) {
+                fe_store(dots + 2 * row, a);
+                fe_store(dots + 2 * (dots_stride + row), b);
+                fe_store(dots + 2 * (2 * dots_stride + row), c);
+            }
+        }
+    }
+    // wave reduction, then one LDS atomic per wave, one global atomic pair per block
+    for (int off = 32; off > 0; off >>= 1) {
+        my_bad += __shfl_down(my_bad, off, 64);
+        const unsigned long long o = __shfl_down(my_first, off, 64);
+        my_first = o < my_first ? o : my_first;
+    }
+    if ((threadIdx.x & 63) == 0 && my_bad) {
+        atomicAdd(&s_bad, my_bad);
+        atomicMin(&s_first, my_first);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_bad) {
+        atomicAdd(&result[0], s_bad);
+        atomicMin(&result[1], s_first);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NTT (replaces galois-fft `FFT.fft` / `FFT.interpolate`; call sites src/QAP.hs:521-524).
+// v1: bit-reversal permutation + one radix-2 DIT stage per launch, twiddles from a table
+// tw[j] = omega_N^j (j < N/2).  Batched: `batch` contiguous transforms of length 2^log_n.
+
+// tw[j] = base^j for j < count
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_pow_table(uint4* __restrict__ tw, u64 count, FeArg base_arg) {
+    const Fe base = fe_from_arg(base_arg);
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < count; j += (u64)gridDim.x * kBlock)
+        fe_store(tw + 2 * j, fe_pow<F>(base, j));
+}
+
+__global__ __launch_bounds__(kBlock) void k_bitrev_permute(uint4* __restrict__ data, u32 log_n, u64 batch) {
+    const u64 n = 1ull << log_n;
+    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < n * batch; t += (u64)gridDim.x * kBlock) {
+        const u64 b = t >> log_n;
+        const u32 i = (u32)(t & (n - 1));
+        const u32 j = log_n ? (__brev(i) >> (32 - log_n)) : 0;
+        if (j > i) {
+            uint4* x = data + 2 * ((b << log_n) + i);
+            uint4* y = data + 2 * ((b << log_n) + j);
+            const uint4 x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+            x[0] = y0; x[1] = y1; y[0] = x0; y[1] = x1;
+        }
+    }
+}
+
+// one DIT stage: butterflies (i0, i0 + half) with twiddle tw[j * (N / (2 half))]
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_ntt_stage(uint4* __restrict__ data, const uint4* __restrict__ tw,
+                                                     u32 log_n, u32 log_half, u64 batch) {
+    const u64 n = 1ull << log_n, half = 1ull << log_half;
+    const u64 total = (n >> 1) * batch;
+    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < total; t += (u64)gridDim.x * kBlock) {
+        const u64 b = t >> (log_n - 1);
+        const u64 bf = t & ((n >> 1) - 1);
+        const u64 j = bf & (half - 1), grp = bf >> log_half;
+        const u64 i0 = (b << log_n) + (grp << (log_half + 1)) + j, i1 = i0 + half;
+        const Fe u = fe_load(data + 2 * i0);
+        const Fe v = fe_load(data + 2 * i1);
+        const Fe wv = fe_mul<F>(v, fe_load(tw + 2 * (j << (log_n - 1 - log_half))));
+        fe_store(data + 2 * i0, fe_add<F>(u, wv));
+        fe_store(data + 2 * i1, fe_sub<F>(u, wv));
+    }
+}
+
+// x[i] *= scale * base^i   (coset shift before a forward transform; N^-1 * g^-i after an inverse)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_scale_powers(uint4* __restrict__ data, u32 log_n, u64 batch,
+                                                        FeArg scale_arg, FeArg base_arg, int use_base) {
+    const Fe scale = fe_from_arg(scale_arg), base = fe_from_arg(base_arg);
+    const u64 n = 1ull << log_n;
+    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < n * batch; t += (u64)gridDim.x * kBlock) {
+        Fe x = fe_mul<F>(fe_load(data + 2 * t), scale);
+        if (use_base) x = fe_mul<F>(x, fe_pow<F>(base, t & (n - 1)));
+        fe_store(data + 2 * t, x);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: h on the coset: a[i] = (a[i]*b[i] - c[i]) * zinv   (src/QAP.hs:325-327 in evaluation form)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_pointwise_h(uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                       const uint4* __restrict__ c, u64 n, FeArg zinv_arg) {
+    const Fe zinv = fe_from_arg(zinv_arg);
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
+        const Fe t = fe_sub<F>(fe_mul<F>(fe_load(a + 2 * i), fe_load(b + 2 * i)), fe_load(c + 2 * i));
+        fe_store(a + 2 * i, fe_mul<F>(t, zinv));
+    }
+}
+
+// h += d1 * R0 + d2 * L0 elementwise (zero-knowledge shift, src/QAP.hs:315-323)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_axpy2(uint4* __restrict__ h, const uint4* __restrict__ x,
+                                                 const uint4* __restrict__ y, u64 n, FeArg ax_arg, FeArg ay_arg) {
+    const Fe ax = fe_from_arg(ax_arg), ay = fe_from_arg(ay_arg);
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
+        Fe t = fe_add<F>(fe_load(h + 2 * i), fe_mul<F>(ax, fe_load(x + 2 * i)));
+        t = fe_add<F>(t, fe_mul<F>(ay, fe_load(y + 2 * i)));
+        fe_store(h + 2 * i, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: densify columns [wire_begin, wire_begin+wire_count) of one matrix from its CSC form into
+// out[w][0..N) (zero filled beforehand) -- the per-wire `Map root value` of the GenQAP
+// (src/QAP.hs:94-99) after `addMissingZeroes` (src/QAP.hs:566-576), only for a batch of wires.
+__global__ __launch_bounds__(kBlock) void k_scatter_columns(const u32* __restrict__ colptr,
+                                                           const u32* __restrict__ rowidx,
+                                                           const uint4* __restrict__ val, u64 wire_begin,
+                                                           u64 wire_count, u32 log_n, uint4* __restrict__ out) {
+    const u64 e_begin = colptr[wire_begin], e_end = colptr[wire_begin + wire_count];
+    for (u64 e = e_begin + (u64)blockIdx.x * kBlock + threadIdx.x; e < e_end; e += (u64)gridDim.x * kBlock) {
+        // locate the column of entry e by binary search in colptr[wire_begin .. wire_begin+wire_count]
+        u64 lo = wire_begin, hi = wire_begin + wire_count;
+        while (hi - lo > 1) {
+            const u64 mid = (lo + hi) >> 1;
+            if (colptr[mid] <= e) lo = mid; else hi = mid;
+        }
+        uint4* dst = out + 2 * (((lo - wire_begin) << log_n) + rowidx[e]);
+        dst[0] = val[2 * e];
+        dst[1] = val[2 * e + 1];
+    }
+}
+
+}  // namespace acx

@@ -1,0 +1,250 @@
+"""Low-level object wrappers over the C ABI (include/acx.h): Context, Circuit, R1CS.
+
+Bulk data crosses as numpy arrays: field elements are uint64 arrays of shape (..., 4)
+(32-byte little-endian canonical integers)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import AcxError, check
+
+FIELDS = {
+    "bn254": (_lib.FIELD_BN254_FR, 21888242871839275222246405745257275088548364400416034343698204186575808495617),
+    "bls12_381": (_lib.FIELD_BLS12_381_FR, 52435875175126190479447740508185965837690552500527637822603658699938581184513),
+}
+_MASK64 = (1 << 64) - 1
+
+
+def ints_to_fr(xs: Sequence[int]) -> np.ndarray:
+    """Python ints (already reduced to [0,p)) -> (len, 4) uint64."""
+    buf = b"".join(int(x).to_bytes(32, "little") for x in xs)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+
+
+def fr_to_ints(a: np.ndarray) -> List[int]:
+    raw = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4).tobytes()
+    return [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
+
+
+def _ptr(a: Optional[np.ndarray]) -> Optional[int]:
+    return None if a is None else a.ctypes.data
+
+
+def _fr_array(a, count: Optional[int] = None) -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    if count is not None and arr.shape[0] != count:
+        raise ValueError(f"expected {count} field elements, got {arr.shape[0]}")
+    return arr
+
+
+class Context:
+    """acx_ctx: one field on one GPU.  Replaces the `GaloisField k` dictionary and the
+    `getRootOfUnity` argument of the reference (src/QAP.hs:513-514)."""
+
+    def __init__(self, field: str = "bn254", device: int = 0):
+        self.lib = _lib.load()
+        self.field = field
+        code, self.p = FIELDS[field]
+        h = C.c_void_p()
+        check(self.lib.acx_ctx_create(code, device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.acx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def root_of_unity(self, k: int) -> int:
+        out = np.zeros(4, dtype=np.uint64)
+        check(self.lib.acx_ctx_root_of_unity(self._h, k, _ptr(out)))
+        return fr_to_ints(out)[0]
+
+    def set_root(self, two_adicity: int, omega: int) -> None:
+        w = ints_to_fr([omega])
+        check(self.lib.acx_ctx_set_root(self._h, two_adicity, _ptr(w)))
+
+    def sync(self) -> None:
+        check(self.lib.acx_ctx_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.acx_ctx_stream(self._h) or 0)
+
+    def ntt(self, data: np.ndarray, log_n: int, inverse: bool = False, shift: Optional[int] = None) -> np.ndarray:
+        n = 1 << log_n
+        arr = _fr_array(data)
+        if arr.shape[0] % n:
+            raise ValueError("data length is not a multiple of 2^log_n")
+        out = np.empty_like(arr)
+        sh = ints_to_fr([shift]) if shift is not None else None
+        check(self.lib.acx_ntt(self._h, log_n, arr.shape[0] // n, int(inverse), _ptr(sh), _ptr(arr), _ptr(out)))
+        return out.reshape(np.asarray(data).shape)
+
+    # device-pointer API (pointers are integers, e.g. torch.Tensor.data_ptr())
+    def dev_from_canonical(self, count: int, d_in: int, d_out: int, d_err: int = 0) -> None:
+        check(self.lib.acx_dev_from_canonical(self._h, count, d_in, d_out, d_err or None))
+
+    def dev_to_canonical(self, count: int, d_in: int, d_out: int) -> None:
+        check(self.lib.acx_dev_to_canonical(self._h, count, d_in, d_out))
+
+    def ntt_dev(self, d_data: int, log_n: int, batch: int = 1, inverse: bool = False, shift: Optional[int] = None) -> None:
+        sh = ints_to_fr([shift]) if shift is not None else None
+        check(self.lib.acx_ntt_dev(self._h, log_n, batch, int(inverse), _ptr(sh), d_data))
+
+
+class R1CS:
+    """acx_r1cs: a device-resident GenQAP in row (constraint) form."""
+
+    def __init__(self, ctx: Context, handle: C.c_void_p):
+        self.ctx = ctx
+        self._h = handle
+        n, m, log_n = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        nnz = (C.c_uint64 * 3)()
+        check(ctx.lib.acx_r1cs_dims(handle, C.byref(n), C.byref(m), C.byref(log_n), C.byref(nnz)))
+        self.n, self.m, self.log_n, self.nnz = n.value, m.value, log_n.value, tuple(nnz)
+
+    @classmethod
+    def load(cls, ctx: Context, n: int, m: int, A, B, Cm) -> "R1CS":
+        keep, structs = [], []
+        for rowptr, col, val in (A, B, Cm):
+            rp = np.ascontiguousarray(rowptr, dtype=np.uint32)
+            cl = np.ascontiguousarray(col, dtype=np.uint32)
+            vl = _fr_array(val)
+            if rp.shape[0] != n + 1 or cl.shape[0] != vl.shape[0] or (n and int(rp[-1]) != cl.shape[0]):
+                raise ValueError("inconsistent CSR arrays")
+            keep.append((rp, cl, vl))
+            structs.append(_lib.Csr(_ptr(rp), _ptr(cl), _ptr(vl)))
+        h = C.c_void_p()
+        check(ctx.lib.acx_r1cs_load(ctx._h, n, m, C.byref(structs[0]), C.byref(structs[1]), C.byref(structs[2]), C.byref(h)))
+        return cls(ctx, h)
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx.lib.acx_r1cs_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def export(self, matrix: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        rowptr = np.zeros(self.n + 1, dtype=np.uint32)
+        col = np.zeros(self.nnz[matrix], dtype=np.uint32)
+        val = np.zeros((self.nnz[matrix], 4), dtype=np.uint64)
+        check(self.ctx.lib.acx_r1cs_export(self._h, matrix, _ptr(rowptr), _ptr(col), _ptr(val)))
+        return rowptr, col, val
+
+    def verify(self, witness: np.ndarray) -> Tuple[bool, int, int]:
+        w = _fr_array(witness, self.m)
+        ok, nbad, first = C.c_int(), C.c_uint64(), C.c_uint64()
+        check(self.ctx.lib.acx_r1cs_verify(self._h, _ptr(w), C.byref(ok), C.byref(nbad), C.byref(first)))
+        return bool(ok.value), nbad.value, first.value
+
+    def residuals(self, witness: np.ndarray) -> np.ndarray:
+        w = _fr_array(witness, self.m)
+        out = np.zeros((self.n, 4), dtype=np.uint64)
+        check(self.ctx.lib.acx_r1cs_residuals(self._h, _ptr(w), _ptr(out)))
+        return out
+
+    def qap_h(self, witness: np.ndarray, delta: Optional[Sequence[int]] = None) -> Tuple[Optional[np.ndarray], bool]:
+        w = _fr_array(witness, self.m)
+        N = 1 << self.log_n
+        out = np.zeros((N + 1, 4), dtype=np.uint64)
+        dl = ints_to_fr(list(delta)) if delta is not None else None
+        hlen, ok = C.c_uint64(), C.c_int()
+        check(self.ctx.lib.acx_qap_h(self._h, _ptr(w), _ptr(dl), _ptr(out), C.byref(hlen), C.byref(ok)))
+        return (out[: hlen.value] if ok.value else None), bool(ok.value)
+
+    def qap_columns(self, matrix: int, wire_begin: int, wire_count: int) -> Tuple[np.ndarray, np.ndarray]:
+        N = 1 << self.log_n
+        out = np.zeros((wire_count, N, 4), dtype=np.uint64)
+        lens = np.zeros(wire_count, dtype=np.uint64)
+        check(self.ctx.lib.acx_qap_columns(self._h, matrix, wire_begin, wire_count, _ptr(out), _ptr(lens)))
+        return out, lens
+
+    def verify_dev(self, d_witness: int, d_result: int, row_offset: int = 0, d_residuals: int = 0, d_dots: int = 0) -> None:
+        check(self.ctx.lib.acx_r1cs_verify_dev(self._h, d_witness, row_offset, d_result, d_residuals or None, d_dots or None))
+
+
+class Circuit:
+    """acx_circuit: a marshalled `ArithCircuit` (pure host object: needs no GPU)."""
+
+    def __init__(self, field: str, gate_list: "_lib.GateList", keep):
+        self.lib = _lib.load()
+        self.field = field
+        self._keep = keep
+        h = C.c_void_p()
+        check(self.lib.acx_circuit_create(FIELDS[field][0], C.byref(gate_list), C.byref(h)))
+        self._h = h
+        vals = [C.c_uint64() for _ in range(5)]
+        check(self.lib.acx_circuit_dims(h, *[C.byref(v) for v in vals]))
+        self.n_rows, self.m, self.n_inputs, self.n_intermediates, self.n_outputs = [v.value for v in vals]
+        self.n_gates = gate_list.n_gates
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.acx_circuit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rows_per_gate(self) -> np.ndarray:
+        out = np.zeros(max(self.n_gates, 1), dtype=np.uint32)
+        check(self.lib.acx_circuit_rows_per_gate(self._h, _ptr(out)))
+        return out[: self.n_gates]
+
+    def valid(self) -> bool:
+        v = C.c_int()
+        check(self.lib.acx_circuit_valid(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def eval(self, inputs: np.ndarray, present: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        inp = _fr_array(inputs) if len(inputs) else np.zeros((0, 4), dtype=np.uint64)
+        pres = np.ascontiguousarray(present, dtype=np.uint8) if present is not None else None
+        w = np.zeros((self.m, 4), dtype=np.uint64)
+        assigned = np.zeros(self.m, dtype=np.uint8)
+        check(self.lib.acx_circuit_eval(self._h, _ptr(inp), _ptr(pres), inp.shape[0], _ptr(w), _ptr(assigned)))
+        return w, assigned
+
+    def rows(self, roots: Optional[np.ndarray] = None):
+        """Host CSR triple [(rowptr, col, val)] x 3 of `arithCircuitToGenQAP` (pure host)."""
+        nnz = (C.c_uint64 * 3)()
+        check(self.lib.acx_circuit_nnz(self._h, C.byref(nnz)))
+        r = _fr_array(roots) if roots is not None else None
+        out = []
+        for k in range(3):
+            rowptr = np.zeros(self.n_rows + 1, dtype=np.uint32)
+            col = np.zeros(nnz[k], dtype=np.uint32)
+            val = np.zeros((nnz[k], 4), dtype=np.uint64)
+            check(self.lib.acx_circuit_rows(self._h, _ptr(r), 0 if r is None else r.shape[0], k,
+                                            _ptr(rowptr), _ptr(col), _ptr(val)))
+            out.append((rowptr, col, val))
+        return out
+
+    def to_r1cs(self, ctx: Context, roots: Optional[np.ndarray] = None) -> R1CS:
+        if ctx.field != self.field:
+            raise ValueError("context and circuit are over different fields")
+        h = C.c_void_p()
+        if roots is None:
+            check(self.lib.acx_circuit_to_r1cs(ctx._h, self._h, None, 0, C.byref(h)))
+        else:
+            r = _fr_array(roots)
+            check(self.lib.acx_circuit_to_r1cs(ctx._h, self._h, _ptr(r), r.shape[0], C.byref(h)))
+        return R1CS(ctx, h)

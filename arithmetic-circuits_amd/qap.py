@@ -1,0 +1,188 @@
+"""Drop-in mirror of the reference's `QAP` module (export list src/QAP.hs:11-39) for the hot
+path: same function names, argument order and results; the bodies marshal across the C ABI into
+the HIP engine.  Differences forced by the boundary are stated per function.
+
+  QapSet                       src/QAP.hs:66-71
+  GenQAP / QAP                 src/QAP.hs:74-99   (device-resident handles here)
+  arithCircuitToGenQAP         src/QAP.hs:530-539
+  createPolynomialsFFT         src/QAP.hs:512-525
+  arithCircuitToQAPFFT         src/QAP.hs:552-561
+  gateToQAP                    src/QAP.hs:355-363
+  verifyAssignment             src/QAP.hs:276-282
+  verificationWitness[Zk]      src/QAP.hs:292-327
+  generateAssignment[Gate]     src/QAP.hs:579-603
+  qapSetToMap / initialQapSet  src/QAP.hs:591-620
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .circuit import ArithCircuit, Equal, Gate, Mul, Split, Wire
+from .engine import Circuit, Context, R1CS, fr_to_ints, ints_to_fr
+
+
+@dataclass
+class QapSet:
+    """`data QapSet f` -- constant, inputs, intermediates, outputs (src/QAP.hs:66-71)."""
+    qapSetConstant: int
+    qapSetInput: Dict[int, int] = field(default_factory=dict)
+    qapSetIntermediate: Dict[int, int] = field(default_factory=dict)
+    qapSetOutput: Dict[int, int] = field(default_factory=dict)
+
+
+def initialQapSet(inputs: Dict[int, int]) -> QapSet:
+    return QapSet(1, dict(inputs))
+
+
+def lookupAtWire(wire: Wire, qs: QapSet) -> Optional[int]:
+    return (qs.qapSetInput, qs.qapSetIntermediate, qs.qapSetOutput)[wire.kind].get(wire.index)
+
+
+def qapSetToMap(qs: QapSet) -> Dict[int, int]:
+    def max_key(m):
+        return max(m) + 1 if m else 0
+    n_in, n_mid = max_key(qs.qapSetInput), max_key(qs.qapSetIntermediate)
+    out = {0: qs.qapSetConstant}
+    out.update({1 + k: v for k, v in qs.qapSetInput.items()})
+    out.update({1 + n_in + k: v for k, v in qs.qapSetIntermediate.items()})
+    out.update({1 + n_in + n_mid + k: v for k, v in qs.qapSetOutput.items()})
+    return out
+
+
+class GenQAP:
+    """`GenQAP (Map k) k`: the evaluation-form QAP.  Here: a device-resident sparse constraint
+    system (never densified) plus the circuit's wire numbering."""
+
+    def __init__(self, ctx: Context, r1cs: R1CS, n_inputs: int, n_intermediates: int, n_outputs: int):
+        self.ctx, self.r1cs = ctx, r1cs
+        self.n_inputs, self.n_intermediates, self.n_outputs = n_inputs, n_intermediates, n_outputs
+
+    def flat_index(self, wire: Wire) -> int:
+        base = (1, 1 + self.n_inputs, 1 + self.n_inputs + self.n_intermediates)[wire.kind]
+        return base + wire.index
+
+    def witness_vector(self, assignment: QapSet) -> np.ndarray:
+        """Flat w[m]; wires the QAP does not know contribute nothing, wires the assignment lacks
+        are 0 (`combineWithDefaults`, src/QAP.hs:163-181,314)."""
+        p = self.ctx.p
+        vals = [0] * self.r1cs.m
+        vals[0] = assignment.qapSetConstant % p
+        for part, base, size in ((assignment.qapSetInput, 1, self.n_inputs),
+                                 (assignment.qapSetIntermediate, 1 + self.n_inputs, self.n_intermediates),
+                                 (assignment.qapSetOutput, 1 + self.n_inputs + self.n_intermediates, self.n_outputs)):
+            for k, v in part.items():
+                if 0 <= k < size:
+                    vals[base + k] = v % p
+        return ints_to_fr(vals)
+
+
+class QAP:
+    """`data QAP f` for the FFT path: qapTarget = x^N - 1; the per-wire polynomials are
+    materialised on demand (3*m*N coefficients do not fit any memory at bench sizes)."""
+
+    def __init__(self, gen: GenQAP):
+        self.gen = gen
+
+    @property
+    def qapTarget(self) -> List[int]:
+        N = 1 << self.gen.r1cs.log_n
+        return [self.gen.ctx.p - 1] + [0] * (N - 1) + [1]
+
+    def _polys(self, matrix: int, wire: Wire = None, flat: int = None) -> List[int]:
+        k = flat if flat is not None else self.gen.flat_index(wire)
+        coeffs, lens = self.gen.r1cs.qap_columns(matrix, k, 1)
+        return fr_to_ints(coeffs[0, : int(lens[0])])
+
+    def qapInputsLeft(self, wire: Wire = None, flat: int = None) -> List[int]:
+        return self._polys(0, wire, flat)
+
+    def qapInputsRight(self, wire: Wire = None, flat: int = None) -> List[int]:
+        return self._polys(1, wire, flat)
+
+    def qapOutputs(self, wire: Wire = None, flat: int = None) -> List[int]:
+        return self._polys(2, wire, flat)
+
+
+def _roots_array(p: int, roots: Optional[Sequence[Sequence[int]]], rows_per_gate) -> Optional[np.ndarray]:
+    if roots is None:
+        return None
+    flat: List[int] = []
+    for g, rs in enumerate(roots):
+        if g < len(rows_per_gate) and len(rs) != int(rows_per_gate[g]):
+            # the reference panics here (src/QAP.hs:445,474); surface the same condition
+            from ._lib import AcxError, STATUS
+            raise AcxError(STATUS["ROOT_COUNT"], "gateToGenQAP: wrong number of roots supplied")
+        flat += [r % p for r in rs]
+    return ints_to_fr(flat) if flat else np.zeros((0, 4), dtype=np.uint64)
+
+
+def arithCircuitToGenQAP(ctx: Context, roots: Optional[Sequence[Sequence[int]]], circuit: ArithCircuit) -> GenQAP:
+    """src/QAP.hs:530-539.  `roots` = one list per gate (None = fresh numbering)."""
+    if roots is not None and len(roots) < len(circuit.gates):
+        circuit = ArithCircuit(circuit.gates[: len(roots)])   # zipWith truncates to the shorter list
+    c = circuit.marshal(ctx.field)
+    r = c.to_r1cs(ctx, _roots_array(ctx.p, roots, c.rows_per_gate()))
+    return GenQAP(ctx, r, c.n_inputs, c.n_intermediates, c.n_outputs)
+
+
+def createPolynomialsFFT(gen: GenQAP) -> QAP:
+    """src/QAP.hs:512-525.  The `primRoots` argument lives in the Context."""
+    return QAP(gen)
+
+
+def arithCircuitToQAPFFT(ctx: Context, roots, circuit: ArithCircuit) -> QAP:
+    return createPolynomialsFFT(arithCircuitToGenQAP(ctx, roots, circuit))
+
+
+def gateToQAP(ctx: Context, roots: Sequence[int], gate: Gate) -> QAP:
+    return arithCircuitToQAPFFT(ctx, [list(roots)], ArithCircuit([gate]))
+
+
+def verifyAssignment(qap: QAP, assignment: QapSet) -> bool:
+    ok, _, _ = qap.gen.r1cs.verify(qap.gen.witness_vector(assignment))
+    return ok
+
+
+def verificationWitnessZk(delta1: int, delta2: int, delta3: int, qap: QAP, assignment: QapSet) -> Optional[List[int]]:
+    p = qap.gen.ctx.p
+    h, ok = qap.gen.r1cs.qap_h(qap.gen.witness_vector(assignment), [delta1 % p, delta2 % p, delta3 % p])
+    return fr_to_ints(h) if ok else None
+
+
+def verificationWitness(qap: QAP, assignment: QapSet) -> Optional[List[int]]:
+    return verificationWitnessZk(0, 0, 0, qap, assignment)
+
+
+def _assignment_from_flat(c: Circuit, w: np.ndarray, assigned: np.ndarray) -> QapSet:
+    vals = fr_to_ints(w)
+    qs = QapSet(vals[0])
+    base = 1
+    for part, size in ((qs.qapSetInput, c.n_inputs), (qs.qapSetIntermediate, c.n_intermediates),
+                       (qs.qapSetOutput, c.n_outputs)):
+        for k in range(size):
+            if assigned[base + k]:
+                part[k] = vals[base + k]
+        base += size
+    return qs
+
+
+def generateAssignment(circuit: ArithCircuit, inputs: Dict[int, int], field: str = "bn254") -> QapSet:
+    """src/QAP.hs:597-603 (host-sequential, like the reference; needs no GPU)."""
+    from .engine import FIELDS
+    p = FIELDS[field][1]
+    c = circuit.marshal(field)
+    n = max(list(inputs) + [-1]) + 1
+    vals = [inputs.get(i, 0) % p for i in range(n)]
+    present = np.array([1 if i in inputs else 0 for i in range(n)], dtype=np.uint8)
+    w, assigned = c.eval(ints_to_fr(vals) if n else np.zeros((0, 4), dtype=np.uint64), present)
+    qs = _assignment_from_flat(c, w, assigned)
+    for i, v in inputs.items():          # inputs the circuit never mentions stay in the QapSet
+        qs.qapSetInput.setdefault(i, v % p)
+    return qs
+
+
+def generateAssignmentGate(gate: Gate, inputs: Dict[int, int], field: str = "bn254") -> QapSet:
+    return generateAssignment(ArithCircuit([gate]), inputs, field)

@@ -1,0 +1,140 @@
+"""Synthetic random circuits for parity tests at scale and for bench.py.
+
+`mulgraph(n, n_in, k, window, seed)`: n `Mul` gates; each side is sum_t s_t * Var(x_t) (+ a
+ConstGate with probability 1/3, mirroring test/Test/Circuit/Arithmetic.hs:59-64); x_t is an input
+w.p. 1/2, else one of the last `window` intermediate outputs; gate g writes IntermediateWire g,
+the last gate OutputWire 0.  All randomness is counter-based (SplitMix64 on (seed, stream,
+index)) so any party regenerates identical bytes.  The marshalled gate list is built directly as
+flat numpy arrays (no per-gate Python objects), then handed to the C ABI like any other circuit."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .engine import Circuit, FIELDS
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _stream(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        base = splitmix64(np.uint64(seed) ^ (np.uint64(stream) * np.uint64(0xD1342543DE82EF95)))
+        return splitmix64(idx.astype(np.uint64) * np.uint64(0x2545F4914F6CDD1D) + base)
+
+
+def random_fr(count: int, seed: int, stream: int, field: str = "bn254") -> np.ndarray:
+    """`count` uniform elements of [0,p) as (count,4) uint64, by rejection sampling."""
+    p = FIELDS[field][1]
+    bits = p.bit_length()
+    top_mask = np.uint64((1 << (bits - 192)) - 1)
+    pl = [np.uint64((p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for i in range(4)]
+    out = np.zeros((count, 4), dtype=np.uint64)
+    pending = np.arange(count, dtype=np.uint64)
+    for attempt in range(24):
+        if pending.size == 0:
+            break
+        cand = np.empty((pending.size, 4), dtype=np.uint64)
+        for j in range(4):
+            cand[:, j] = _stream(seed, stream * 4 + j, pending * np.uint64(32) + np.uint64(attempt))
+        cand[:, 3] &= top_mask
+        lt = np.zeros(pending.size, dtype=bool)
+        eq = np.ones(pending.size, dtype=bool)
+        for j in (3, 2, 1, 0):
+            lt |= eq & (cand[:, j] < pl[j])
+            eq &= cand[:, j] == pl[j]
+        out[pending[lt]] = cand[lt]
+        pending = pending[~lt]
+    if pending.size:  # astronomically unlikely; stay deterministic
+        out[pending, 0] = pending
+    return out
+
+
+@dataclass
+class SynthCircuit:
+    circuit: Circuit           # marshalled (host) circuit
+    inputs: np.ndarray         # (n_in, 4) canonical
+    n: int
+    n_in: int
+    k: int
+
+    def rows(self):
+        return self.circuit.rows()
+
+    def witness(self) -> np.ndarray:
+        w, _ = self.circuit.eval(self.inputs)
+        return w
+
+
+def mulgraph(n: int, n_in: int = 1024, k: int = 2, window: int = 4096, seed: int = 0xAC355,
+             field: str = "bn254") -> SynthCircuit:
+    if n < 1 or n_in < 1 or k < 1:
+        raise ValueError("n, n_in, k must be positive")
+    sides = 2 * n
+    side_idx = np.arange(sides, dtype=np.uint64)
+    gate_of_side = (side_idx // np.uint64(2)).astype(np.int64)
+    has_const = (_stream(seed, 1, side_idx) % np.uint64(3)) == 0
+    # term wires
+    t_idx = np.arange(sides * k, dtype=np.uint64)
+    gate_of_term = np.repeat(gate_of_side, k)
+    use_mid = ((_stream(seed, 2, t_idx) & np.uint64(1)) == 1) & (gate_of_term > 0)
+    r = _stream(seed, 3, t_idx)
+    span = np.minimum(gate_of_term, window).astype(np.uint64)
+    span_safe = np.maximum(span, np.uint64(1))
+    mid_index = gate_of_term.astype(np.uint64) - np.uint64(1) - (r % span_safe)
+    inp_index = r % np.uint64(n_in)
+    aff_wires = np.zeros((sides * k, 2), dtype=np.uint32)
+    aff_wires[:, 0] = use_mid.astype(np.uint32)          # 1 = IntermediateWire, 0 = InputWire
+    aff_wires[:, 1] = np.where(use_mid, mid_index, inp_index).astype(np.uint32)
+    # scalars: k coefficients per side, then one constant per side that has one
+    coeff = random_fr(sides * k, seed, 10, field)
+    n_const = int(has_const.sum())
+    consts = random_fr(n_const, seed, 11, field)
+    scalars = np.concatenate([coeff, consts], axis=0)
+    const_slot = np.cumsum(has_const) - 1 + sides * k       # scalar index of a side's constant
+    # tokens per side: (k-1) ADDs [+1 ADD if const], k x (SMUL, VAR) [, CONST]
+    #   pre-order of  Add(t1, Add(t2, ... Add(t_k, const)))   /   Add(t1, ... Add(t_{k-1}, t_k))
+    tok_per_side = (3 * k - 1) + np.where(has_const, 2, 0)
+    side_ofs = np.concatenate([[0], np.cumsum(tok_per_side)]).astype(np.int64)
+    n_tok = int(side_ofs[-1])
+    tok_op = np.zeros(n_tok, dtype=np.uint8)
+    tok_arg = np.zeros(n_tok, dtype=np.uint32)
+    base = side_ofs[:-1]
+    n_adds = (k - 1) + has_const.astype(np.int64)
+    for t in range(k):
+        # position of term t: ADDs interleave: ADD t1 ADD t2 ... ; term t preceded by min(t+1, n_adds) ADDs
+        adds_before = np.minimum(t + 1, n_adds)
+        pos = base + adds_before + 2 * t
+        # mark the ADD that precedes this term (if any new one)
+        new_add = adds_before > np.minimum(t, n_adds)
+        tok_op[(pos - 1)[new_add]] = 0
+        tok_op[pos] = 1
+        tok_arg[pos] = (np.arange(sides) * k + t).astype(np.uint32)
+        tok_op[pos + 1] = 3
+        tok_arg[pos + 1] = (np.arange(sides) * k + t).astype(np.uint32)
+    cpos = (base + n_adds + 2 * k)[has_const]
+    tok_op[cpos] = 2
+    tok_arg[cpos] = const_slot[has_const].astype(np.uint32)
+    tok_ofs = side_ofs.astype(np.uint64)
+    kind = np.zeros(n, dtype=np.uint8)
+    wires = np.zeros((n, 2), dtype=np.uint32)
+    wires[:, 0] = 1
+    wires[:, 1] = np.arange(n, dtype=np.uint32)
+    wires[n - 1] = (2, 0)                                  # last gate -> OutputWire 0
+    wire_ofs = np.arange(n + 1, dtype=np.uint64)
+    gl = _lib.GateList(n, kind.ctypes.data, tok_ofs.ctypes.data, tok_op.ctypes.data, tok_arg.ctypes.data,
+                       scalars.ctypes.data, scalars.shape[0], aff_wires.ctypes.data, aff_wires.shape[0],
+                       wire_ofs.ctypes.data, wires.ctypes.data)
+    circ = Circuit(field, gl, (kind, tok_ofs, tok_op, tok_arg, scalars, aff_wires, wire_ofs, wires))
+    inputs = random_fr(n_in, seed, 12, field)
+    return SynthCircuit(circ, inputs, n, n_in, k)

