@@ -66,6 +66,7 @@ struct acx_r1cs {
     uint32_t log_n = 0;
     DevMatrix M[3];
     DevMatrix T[3];        // CSC, built lazily for acx_qap_columns
+    bool unit_c = false;   // every stored C value is 1: the kernel never reads C's value stream
     bool has_csc = false;
     uint4* d_w = nullptr;  // witness staging, m elements
 };
@@ -205,8 +206,12 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
     CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val},
         C{r->M[2].ptr, r->M[2].idx, r->M[2].val};
     const int grid = grid_for(c, r->n, 16);
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_residual<F>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C, d_w,
-                                         r->n, row_offset, d_result, d_res, d_dots, dots_stride));
+    DISPATCH_FIELD(c, {
+        if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual<F, true>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
+                                          d_w, r->n, row_offset, d_result, d_res, d_dots, dots_stride);
+        else hipLaunchKernelGGL((k_r1cs_residual<F, false>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
+                                d_w, r->n, row_offset, d_result, d_res, d_dots, dots_stride);
+    });
     HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
@@ -311,6 +316,12 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
         std::vector<uint32_t> rowptr, col;
         std::vector<acx_fr> val;
         rc = normalise_csr(ctx->hf, n, m, mats[k], rowptr, col, val);
+        if (rc == ACX_OK && k == 2) {
+            static const uint8_t one32[32] = {1};
+            bool unit = true;
+            for (size_t e = 0; e < val.size() && unit; ++e) unit = std::memcmp(val[e].b, one32, 32) == 0;
+            r->unit_c = unit;
+        }
         if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, col, val.data(), true, r->M[k]);
     }
     if (rc == ACX_OK) {

@@ -185,6 +185,57 @@ __device__ __forceinline__ Fe fe_mul(const Fe& a, const Fe& b) {
     return r;
 }
 
+// ---- deferred reduction: sum of raw limb products, one Montgomery reduction per sum --------------
+// Column accumulators of the schoolbook product: c[k] = sum over terms of sum_{i+j=k} a_i b_j.
+// Each v_mad_u64_u32 adds straight into its column (no carry handling at all).  With limbs
+// < 2^29 a column grows by < 9 * 2^58 per term; wide_reduce() adds < 9 * 2^58 + 2^36 more, so at
+// most kWideTerms = 6 terms may be accumulated before reducing ((9*6 + 9) * 2^58 < 2^64).
+constexpr int kWideTerms = 6;
+
+struct Wide {
+    u64 c[2 * kLimbs - 1];
+};
+
+__device__ __forceinline__ void wide_zero(Wide& w) {
+#pragma unroll
+    for (int k = 0; k < 2 * kLimbs - 1; ++k) w.c[k] = 0;
+}
+
+__device__ __forceinline__ void wide_mac(Wide& w, const Fe& a, const Fe& b) {
+#pragma unroll
+    for (int i = 0; i < kLimbs; ++i)
+#pragma unroll
+        for (int j = 0; j < kLimbs; ++j) w.c[i + j] += (u64)a.l[i] * b.l[j];
+}
+
+// Montgomery reduction of the accumulated sum T (< 2^64 per column as above): T/R mod p, lazy.
+// For operands < 2p each and <= 6 terms: T/R + p < (24 p/R + 1) p < 2p for both fields.
+template <class F>
+__device__ __forceinline__ Fe wide_reduce(const Wide& w) {
+    u64 t = 0;
+    u32 m[kLimbs];
+    Fe r;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        t += w.c[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) t += (u64)m[i] * F::P[k - i];
+        m[k] = ((u32)t * F::N0) & kLimbMask;
+        t += (u64)m[k] * F::P[0];
+        t >>= kLimbBits;
+    }
+#pragma unroll
+    for (int k = kLimbs; k < 2 * kLimbs - 1; ++k) {
+        t += w.c[k];
+#pragma unroll
+        for (int i = k - kLimbs + 1; i < kLimbs; ++i) t += (u64)m[i] * F::P[k - i];
+        r.l[k - kLimbs] = (u32)t & kLimbMask;
+        t >>= kLimbBits;
+    }
+    r.l[kLimbs - 1] = (u32)t;
+    return r;
+}
+
 // lazy [0,2p) -> canonical residue [0,p) of the same Montgomery value
 template <class F>
 __device__ __forceinline__ Fe fe_reduce(const Fe& a) {

@@ -36,20 +36,39 @@ __global__ __launch_bounds__(kBlock) void k_convert(const uint4* __restrict__ in
 // K2: R1CS residual check = `verifyAssignment` (/root/reference/src/QAP.hs:276-327) in the
 // evaluation domain: r_i = <A_i,w> * <B_i,w> - <C_i,w> for every constraint row i.
 // One row per lane; a row's entries are contiguous in the CSR value stream.
-template <class F>
+// <M_row, w> with deferred reduction: raw limb products of up to kWideTerms entries are summed in
+// 64-bit column accumulators and Montgomery-reduced once (81 mads per entry + ~100 per row
+// instead of 171 per entry).  UNIT = every stored value of this matrix is the field's 1 (the C
+// matrix of every gate the reference emits, src/QAP.hs:371-474): the dot is a plain sum of
+// witness entries and the value stream is never read.
+template <class F, bool UNIT>
 __device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restrict__ w, u64 row) {
-    Fe acc = fe_zero();
     const u32 e0 = M.rowptr[row], e1 = M.rowptr[row + 1];
-    for (u32 e = e0; e < e1; ++e) {
-        const Fe v = fe_load(M.val + 2 * (u64)e);
-        const Fe x = fe_load(w + 2 * (u64)M.col[e]);
-        acc = fe_add<F>(acc, fe_mul<F>(v, x));
+    Fe acc = fe_zero();
+    if (UNIT) {
+        for (u32 e = e0; e < e1; ++e) {
+            const Fe x = fe_load(w + 2 * (u64)M.col[e]);
+            acc = (e == e0) ? x : fe_add<F>(acc, x);
+        }
+        return acc;
+    }
+    for (u32 base = e0; base < e1; base += kWideTerms) {
+        const u32 end = (e1 - base > (u32)kWideTerms) ? base + kWideTerms : e1;
+        Wide wide;
+        wide_zero(wide);
+        for (u32 e = base; e < end; ++e) {
+            const Fe v = fe_load(M.val + 2 * (u64)e);
+            const Fe x = fe_load(w + 2 * (u64)M.col[e]);
+            wide_mac(wide, v, x);
+        }
+        const Fe part = wide_reduce<F>(wide);
+        acc = (base == e0) ? part : fe_add<F>(acc, part);
     }
     return acc;
 }
 
 // result[0] += number of violated rows; result[1] = min(result[1], first violated global row).
-template <class F>
+template <class F, bool UNIT_C>
 __global__ __launch_bounds__(kBlock) void k_r1cs_residual(CsrDev A, CsrDev B, CsrDev C,
                                                          const uint4* __restrict__ w, u64 n, u64 row_offset,
                                                          unsigned long long* __restrict__ result,
@@ -62,9 +81,9 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_residual(CsrDev A, CsrDev B, Cs
     for (u64 base = (u64)blockIdx.x * kBlock; base < n; base += (u64)gridDim.x * kBlock) {
         const u64 row = base + threadIdx.x;
         if (row < n) {
-            const Fe a = csr_row_dot<F>(A, w, row);
-            const Fe b = csr_row_dot<F>(B, w, row);
-            const Fe c = csr_row_dot<F>(C, w, row);
+            const Fe a = csr_row_dot<F, false>(A, w, row);
+            const Fe b = csr_row_dot<F, false>(B, w, row);
+            const Fe c = csr_row_dot<F, UNIT_C>(C, w, row);
             const Fe r = fe_sub<F>(fe_mul<F>(a, b), c);
             if (!fe_is_zero<F>(r)) {
                 ++my_bad;

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on one GPU (development tool; bench.py is the judged harness).
+usage: python tools/kbench.py [r1cs|ntt|all] [--logn 16 20] [--reps 20]"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+acx = importlib.import_module("arithmetic-circuits_amd")
+synth = importlib.import_module("arithmetic-circuits_amd.synth")
+
+
+def alg_bytes(mats, n):
+    nnz = sum(int(m[1].shape[0]) for m in mats)
+    m_ref = np.unique(np.concatenate([m[1] for m in mats])).shape[0]
+    return 36 * nnz + 12 * (n + 1) + 32 * m_ref + 8, nnz, m_ref
+
+
+def time_stream(stream, fn, reps, warmup=3):
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps   # us
+
+
+def to_dev(ctx, arr):
+    t = torch.from_numpy(arr.view(np.int64).copy()).cuda()
+    ctx.dev_from_canonical(arr.shape[0], t.data_ptr(), t.data_ptr())
+    ctx.sync()
+    return t
+
+
+def bench_r1cs(ctx, stream, log_n, reps, copies):
+    n = 1 << log_n
+    systems = []
+    for c in range(copies):
+        s = synth.mulgraph(n, seed=0xAC355 + c)
+        mats = s.rows()
+        r = s.circuit.to_r1cs(ctx)
+        w = to_dev(ctx, s.witness())
+        systems.append((r, w, mats))
+    b, nnz, m_ref = alg_bytes(systems[0][2], n)
+    res = torch.zeros(2, dtype=torch.int64, device="cuda")
+    res[1] = -1
+    ctx.sync()
+    i = [0]
+
+    def fn():
+        r, w, _ = systems[i[0] % copies]
+        i[0] += 1
+        r.verify_dev(w.data_ptr(), res.data_ptr())
+
+    us = time_stream(stream, fn, reps * copies)
+    ctx.sync()
+    assert int(res[0]) == 0, "witness must verify"
+    print(f"r1cs n=2^{log_n} copies={copies}: {us:9.2f} us/launch  {n / us * 1e6:.3e} constraints/s  "
+          f"alg {b / 1e6:.2f} MB -> {b / us * 1e-3:.1f} GB/s ({b / us * 1e-3 / 8000 * 100:.1f}% of 8 TB/s)  nnz={nnz} m_ref={m_ref}")
+
+
+def bench_ntt(ctx, stream, log_n, reps, batch=1):
+    n = 1 << log_n
+    x = to_dev(ctx, synth.random_fr(n * batch, 5, 1))
+    us = time_stream(stream, lambda: ctx.ntt_dev(x.data_ptr(), log_n, batch, inverse=True), reps)
+    ops = (1.5 * n * log_n + n) * batch
+    print(f"intt N=2^{log_n} batch={batch}: {us:9.2f} us  {ops / us * 1e6:.3e} field-ops/s  "
+          f"alg(128N) {128 * n * batch / us * 1e-3:.1f} GB/s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--logn", type=int, nargs="*", default=[16, 20])
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--copies", type=int, default=4)
+    a = ap.parse_args()
+    ctx = acx.Context("bn254", 0)
+    stream = torch.cuda.ExternalStream(ctx.stream)
+    for ln in a.logn:
+        if a.what in ("r1cs", "all"):
+            bench_r1cs(ctx, stream, ln, a.reps, a.copies if ln <= 18 else 1)
+        if a.what in ("ntt", "all"):
+            bench_ntt(ctx, stream, ln, a.reps)
+
+
+if __name__ == "__main__":
+    main()
