@@ -205,7 +205,9 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
     if (r->n == 0) return ACX_OK;
     CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val},
         C{r->M[2].ptr, r->M[2].idx, r->M[2].val};
-    const int grid = grid_for(c, r->n, 16);
+    // one 256-row tile per workgroup, padded to a multiple of 8 so that the XCD remap is a bijection
+    const uint64_t tiles = (r->n + kBlock - 1) / kBlock;
+    const int grid = (int)(((tiles + 7) / 8) * 8);
     DISPATCH_FIELD(c, {
         if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual<F, true>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
                                           d_w, r->n, row_offset, d_result, d_res, d_dots, dots_stride);

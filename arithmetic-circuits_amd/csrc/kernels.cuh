@@ -78,9 +78,15 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_residual(CsrDev A, CsrDev B, Cs
     if (threadIdx.x == 0) { s_bad = 0; s_first = ~0ull; }
     __syncthreads();
     unsigned long long my_bad = 0, my_first = ~0ull;
-    for (u64 base = (u64)blockIdx.x * kBlock; base < n; base += (u64)gridDim.x * kBlock) {
-        const u64 row = base + threadIdx.x;
-        if (row < n) {
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order), so XCD x is
+    // given the contiguous tile range [x*T/8, (x+1)*T/8): its in-flight rows, and therefore the
+    // witness window they gather from, stay inside that XCD's private 4 MiB L2.
+    const u64 tiles = (n + kBlock - 1) / kBlock;
+    for (u64 t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const u64 per_xcd = (tiles + 7) / 8;
+        const u64 tile = (t & 7) * per_xcd + (t >> 3);
+        const u64 row = tile * kBlock + threadIdx.x;
+        if (tile < tiles && row < n) {
             const Fe a = csr_row_dot<F, false>(A, w, row);
             const Fe b = csr_row_dot<F, false>(B, w, row);
             const Fe c = csr_row_dot<F, UNIT_C>(C, w, row);
