@@ -67,6 +67,13 @@ struct acx_r1cs {
     DevMatrix M[3];
     DevMatrix T[3];        // CSC, built lazily for acx_qap_columns
     bool unit_c = false;   // every stored C value is 1: the kernel never reads C's value stream
+    // SELL-64 layout used by the residual kernel (kernels.cuh)
+    u32* sell_ofs[3] = {nullptr, nullptr, nullptr};
+    u32* sell_col[3] = {nullptr, nullptr, nullptr};
+    uint4* sell_val[3] = {nullptr, nullptr, nullptr};
+    u32* perm = nullptr;
+    u32* long_rows = nullptr;
+    uint32_t n_slices = 0, n_long = 0;
     bool has_csc = false;
     uint4* d_w = nullptr;  // witness staging, m elements
 };
@@ -199,22 +206,113 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
     return ACX_OK;
 }
 
+SellSystem sell_system(const acx_r1cs* r, const uint4* d_w, const ResidualOut& out) {
+    SellSystem S;
+    S.A = SellDev{r->sell_ofs[0], r->sell_col[0], r->sell_val[0]};
+    S.B = SellDev{r->sell_ofs[1], r->sell_col[1], r->sell_val[1]};
+    S.C = SellDev{r->sell_ofs[2], r->sell_col[2], r->sell_val[2]};
+    S.perm = r->perm;
+    S.w = d_w;
+    S.n_slices = r->n_slices;
+    S.unit_c = r->unit_c ? 1u : 0u;
+    S.out = out;
+    return S;
+}
+
+inline unsigned sell_grid_x(uint32_t n_slices) {
+    const uint32_t tiles = (n_slices + 3) / 4;
+    return ((tiles + 7) / 8) * 8;   // multiple of 8: the XCD remap is a bijection
+}
+
+// rows too long for SELL go through the CSR kernel
+int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out) {
+    acx_ctx* c = r->ctx;
+    if (r->n_long == 0) return ACX_OK;
+    CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val},
+        C{r->M[2].ptr, r->M[2].idx, r->M[2].val};
+    const int grid = (int)((r->n_long + kBlock - 1) / kBlock);
+    DISPATCH_FIELD(c, {
+        if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual_rows<F, true>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
+                                          d_w, (const u32*)r->long_rows, r->n_long, out);
+        else hipLaunchKernelGGL((k_r1cs_residual_rows<F, false>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
+                                d_w, (const u32*)r->long_rows, r->n_long, out);
+    });
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
 int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned long long* d_result,
                     uint4* d_res, uint4* d_dots, uint64_t dots_stride) {
     acx_ctx* c = r->ctx;
     if (r->n == 0) return ACX_OK;
-    CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val},
-        C{r->M[2].ptr, r->M[2].idx, r->M[2].val};
-    // one 256-row tile per workgroup, padded to a multiple of 8 so that the XCD remap is a bijection
-    const uint64_t tiles = (r->n + kBlock - 1) / kBlock;
-    const int grid = (int)(((tiles + 7) / 8) * 8);
+    const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset};
+    const SellSystem S = sell_system(r, d_w, out);
+    const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
     DISPATCH_FIELD(c, {
-        if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual<F, true>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
-                                          d_w, r->n, row_offset, d_result, d_res, d_dots, dots_stride);
-        else hipLaunchKernelGGL((k_r1cs_residual<F, false>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
-                                d_w, r->n, row_offset, d_result, d_res, d_dots, dots_stride);
+        if (r->unit_c) hipLaunchKernelGGL((k_r1cs_sell<F, true>), grid, dim3(kBlock), 0, c->stream,
+                                          (const SellSystem*)nullptr, S);
+        else hipLaunchKernelGGL((k_r1cs_sell<F, false>), grid, dim3(kBlock), 0, c->stream,
+                                (const SellSystem*)nullptr, S);
     });
     HIP_TRY(hipGetLastError());
+    return launch_long_rows(r, d_w, out);
+}
+
+// Host side of the SELL-64 layout: row order (sorted by length inside windows), slot offsets, and
+// the list of rows that stay in CSR.  Only row lengths are needed; the entries are gathered on
+// the device by k_build_sell from the already converted CSR.
+int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
+    acx_ctx* c = r->ctx;
+    const uint64_t n = r->n;
+    const uint32_t n_slices = (uint32_t)((n + kSlice - 1) / kSlice);
+    r->n_slices = n_slices;
+    if (n == 0) return ACX_OK;
+    std::vector<uint32_t> key(n), perm((size_t)n_slices * kSlice, kNoRow), longs;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t l[3];
+        bool is_long = false;
+        for (int k = 0; k < 3; ++k) { l[k] = rowptr[k][i + 1] - rowptr[k][i]; is_long = is_long || l[k] > (uint32_t)kSellMaxLen; }
+        key[i] = is_long ? 0xffffffffu : ((l[0] << 16) | (l[1] << 8) | l[2]);
+        if (is_long) longs.push_back((uint32_t)i);
+    }
+    std::vector<uint32_t> idx;
+    for (uint64_t ws = 0; ws < n; ws += kSellWindow) {
+        const uint64_t we = std::min<uint64_t>(ws + kSellWindow, n);
+        idx.resize(we - ws);
+        for (uint64_t i = ws; i < we; ++i) idx[i - ws] = (uint32_t)i;
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        for (uint64_t i = ws; i < we; ++i) perm[i] = key[idx[i - ws]] == 0xffffffffu ? kNoRow : idx[i - ws];
+    }
+    HIP_TRY(hipMalloc((void**)&r->perm, perm.size() * 4));
+    HIP_TRY(hipMemcpyAsync(r->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice, c->stream));
+    r->n_long = (uint32_t)longs.size();
+    if (!longs.empty()) {
+        HIP_TRY(hipMalloc((void**)&r->long_rows, longs.size() * 4));
+        HIP_TRY(hipMemcpyAsync(r->long_rows, longs.data(), longs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<uint32_t> ofs(n_slices + 1);
+    for (int k = 0; k < 3; ++k) {
+        ofs[0] = 0;
+        for (uint32_t s = 0; s < n_slices; ++s) {
+            uint32_t mx = 0;
+            for (int l = 0; l < kSlice; ++l) {
+                const uint32_t row = perm[(size_t)s * kSlice + l];
+                if (row != kNoRow) mx = std::max(mx, rowptr[k][row + 1] - rowptr[k][row]);
+            }
+            ofs[s + 1] = ofs[s] + mx;
+        }
+        const uint64_t slots = ofs[n_slices];
+        HIP_TRY(hipMalloc((void**)&r->sell_ofs[k], ofs.size() * 4));
+        HIP_TRY(hipMalloc((void**)&r->sell_col[k], std::max<uint64_t>(slots, 1) * kSlice * 4));
+        HIP_TRY(hipMalloc((void**)&r->sell_val[k], std::max<uint64_t>(slots, 1) * kSlice * 32));
+        HIP_TRY(hipMemcpyAsync(r->sell_ofs[k], ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // ofs is reused by the next matrix
+        const CsrDev M{r->M[k].ptr, r->M[k].idx, r->M[k].val};
+        hipLaunchKernelGGL(k_build_sell, dim3((n_slices + 3) / 4), dim3(kBlock), 0, c->stream, M, (const u32*)r->perm,
+                           (const u32*)r->sell_ofs[k], n_slices, r->sell_col[k], r->sell_val[k]);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return ACX_OK;
 }
 
@@ -303,6 +401,21 @@ void free_matrix(DevMatrix& mtx) {
     mtx = DevMatrix{};
 }
 
+void free_r1cs_device(acx_r1cs* r) {
+    for (int k = 0; k < 3; ++k) {
+        free_matrix(r->M[k]);
+        free_matrix(r->T[k]);
+        if (r->sell_ofs[k]) (void)hipFree(r->sell_ofs[k]);
+        if (r->sell_col[k]) (void)hipFree(r->sell_col[k]);
+        if (r->sell_val[k]) (void)hipFree(r->sell_val[k]);
+        r->sell_ofs[k] = nullptr; r->sell_col[k] = nullptr; r->sell_val[k] = nullptr;
+    }
+    if (r->perm) (void)hipFree(r->perm);
+    if (r->long_rows) (void)hipFree(r->long_rows);
+    if (r->d_w) (void)hipFree(r->d_w);
+    r->perm = nullptr; r->long_rows = nullptr; r->d_w = nullptr;
+}
+
 int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3], acx_r1cs** out) {
     if (!ctx || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (m == 0 || m >= 0xffffffffull || n >= 0xffffffffull) return fail(ACX_ERR_TOO_LARGE, "n or m out of range");
@@ -314,8 +427,10 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
     if (!r) return fail(ACX_ERR_OOM, "host allocation failed");
     r->ctx = ctx; r->n = n; r->m = m; r->log_n = log_n;
     int rc = ACX_OK;
+    std::vector<uint32_t> rowptrs[3];
     for (int k = 0; k < 3 && rc == ACX_OK; ++k) {
-        std::vector<uint32_t> rowptr, col;
+        std::vector<uint32_t>& rowptr = rowptrs[k];
+        std::vector<uint32_t> col;
         std::vector<acx_fr> val;
         rc = normalise_csr(ctx->hf, n, m, mats[k], rowptr, col, val);
         if (rc == ACX_OK && k == 2) {
@@ -326,13 +441,13 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
         }
         if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, col, val.data(), true, r->M[k]);
     }
+    if (rc == ACX_OK) rc = build_sell(r, rowptrs);
     if (rc == ACX_OK) {
         hipError_t e = hipMalloc((void**)&r->d_w, m * 32);
         if (e != hipSuccess) rc = fail(ACX_ERR_OOM, "witness buffer allocation failed");
     }
     if (rc != ACX_OK) {
-        for (int k = 0; k < 3; ++k) free_matrix(r->M[k]);
-        if (r->d_w) (void)hipFree(r->d_w);
+        free_r1cs_device(r);
         delete r;
         return rc;
     }
@@ -602,8 +717,7 @@ void acx_r1cs_destroy(acx_r1cs* r) {
         std::lock_guard<std::mutex> lock(r->ctx->mu);
         (void)hipSetDevice(r->ctx->device);
         (void)hipStreamSynchronize(r->ctx->stream);
-        for (int k = 0; k < 3; ++k) { free_matrix(r->M[k]); free_matrix(r->T[k]); }
-        if (r->d_w) (void)hipFree(r->d_w);
+        free_r1cs_device(r);
     }
     delete r;
 }

@@ -67,57 +67,171 @@ __device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restri
     return acc;
 }
 
-// result[0] += number of violated rows; result[1] = min(result[1], first violated global row).
-template <class F, bool UNIT_C>
-__global__ __launch_bounds__(kBlock) void k_r1cs_residual(CsrDev A, CsrDev B, CsrDev C,
-                                                         const uint4* __restrict__ w, u64 n, u64 row_offset,
-                                                         unsigned long long* __restrict__ result,
-                                                         uint4* __restrict__ residuals,
-                                                         uint4* __restrict__ dots, u64 dots_stride) {
-    __shared__ unsigned long long s_bad, s_first;
-    if (threadIdx.x == 0) { s_bad = 0; s_first = ~0ull; }
-    __syncthreads();
+// ---- SELL-64 device layout of a constraint matrix -------------------------------------------------
+// Rows are grouped in slices of 64 (one wavefront).  Inside a slice, slot j of all 64 rows is stored
+// together: a wave reading "entry j of my row" issues perfectly coalesced 1 KiB loads and every
+// 128-byte line of the stream is fetched from HBM exactly once.  (A row-per-lane walk over plain
+// CSR touched each line in three loop iterations far apart: measured 2.1x HBM over-fetch,
+// profiles/r01_r1cs_direct_2p22_overfetch.txt; staging CSR through LDS removed the over-fetch but
+// its barriers cost more than it saved, profiles/r01_r1cs_lds_staged_2p22.txt.)  Rows are sorted by
+// length inside windows of kSellWindow rows so that slices are uniform: no padding to stream and no
+// lane idles in the multiply loop.  Rows longer than kSellMaxLen in any matrix (the 2^j row of a
+// Split gate, src/QAP.hs:447-459) stay in CSR and are handled by k_r1cs_residual_rows.
+constexpr int kSlice = 64;
+constexpr int kSellMaxLen = 8;
+constexpr int kSellWindow = 4096;
+constexpr u32 kNoRow = 0xffffffffu;
+
+struct SellDev {
+    const u32* slice_ofs;  // [n_slices + 1] slot offsets
+    const u32* col;        // [slots * 64]; kNoRow marks padding
+    const uint4* val;      // [slots * 2 * 64]: slot q, half h, lane l at (2q + h) * 64 + l
+};
+
+// Gather one matrix from its (device, dev-format) CSR into the SELL arrays.
+__global__ __launch_bounds__(kBlock) void k_build_sell(CsrDev M, const u32* __restrict__ perm,
+                                                      const u32* __restrict__ slice_ofs, u32 n_slices,
+                                                      u32* __restrict__ col, uint4* __restrict__ val) {
+    const u32 slice = blockIdx.x * (kBlock / kSlice) + (threadIdx.x / kSlice);
+    const u32 lane = threadIdx.x % kSlice;
+    if (slice >= n_slices) return;
+    const u32 q0 = slice_ofs[slice], q1 = slice_ofs[slice + 1];
+    const u32 row = perm[slice * kSlice + lane];
+    u32 e0 = 0, len = 0;
+    if (row != kNoRow) { e0 = M.rowptr[row]; len = M.rowptr[row + 1] - e0; }
+    for (u32 q = q0; q < q1; ++q) {
+        const u32 j = q - q0;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        u32 c = kNoRow;
+        if (j < len) { lo = M.val[2 * (u64)(e0 + j)]; hi = M.val[2 * (u64)(e0 + j) + 1]; c = M.col[e0 + j]; }
+        col[(u64)q * kSlice + lane] = c;
+        val[(2 * (u64)q) * kSlice + lane] = lo;
+        val[(2 * (u64)q + 1) * kSlice + lane] = hi;
+    }
+}
+
+template <class F, bool UNIT>
+__device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane) {
+    const u32 q0 = M.slice_ofs[slice], q1 = M.slice_ofs[slice + 1];   // wave-uniform
+    Fe acc = fe_zero();
+    if (UNIT) {
+        for (u32 q = q0; q < q1; ++q) {
+            const u32 c = M.col[(u64)q * kSlice + lane];
+            if (c != kNoRow) acc = fe_add<F>(acc, fe_load(w + 2 * (u64)c));
+        }
+        return acc;
+    }
+    bool have = false;
+    for (u32 base = q0; base < q1; base += kWideTerms) {
+        const u32 end = (q1 - base > (u32)kWideTerms) ? base + kWideTerms : q1;
+        Wide wide;
+        wide_zero(wide);
+        for (u32 q = base; q < end; ++q) {
+            const u32 c = M.col[(u64)q * kSlice + lane];
+            const uint4 lo = M.val[(2 * (u64)q) * kSlice + lane], hi = M.val[(2 * (u64)q + 1) * kSlice + lane];
+            const u32 vw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const Fe x = fe_load(w + 2 * (u64)(c == kNoRow ? 0u : c));   // padding: value 0 * w[0]
+            wide_mac(wide, fe_unpack(vw), x);
+        }
+        const Fe part = wide_reduce<F>(wide);
+        acc = have ? fe_add<F>(acc, part) : part;
+        have = true;
+    }
+    return acc;
+}
+
+struct ResidualOut {
+    unsigned long long* result;  // {n_bad, first_bad}
+    uint4* residuals;            // [n] or null
+    uint4* dots;                 // [3 * stride] or null
+    u64 dots_stride;
+    u64 row_offset;
+};
+
+// per-lane epilogue shared by the SELL and the CSR-rows kernels
+template <class F>
+__device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, const Fe& c, u32 row, bool live,
+                                                  const ResidualOut& out, unsigned long long* s_bad,
+                                                  unsigned long long* s_first) {
     unsigned long long my_bad = 0, my_first = ~0ull;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order), so XCD x is
-    // given the contiguous tile range [x*T/8, (x+1)*T/8): its in-flight rows, and therefore the
-    // witness window they gather from, stay inside that XCD's private 4 MiB L2.
-    const u64 tiles = (n + kBlock - 1) / kBlock;
-    for (u64 t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const u64 per_xcd = (tiles + 7) / 8;
-        const u64 tile = (t & 7) * per_xcd + (t >> 3);
-        const u64 row = tile * kBlock + threadIdx.x;
-        if (tile < tiles && row < n) {
-            const Fe a = csr_row_dot<F, false>(A, w, row);
-            const Fe b = csr_row_dot<F, false>(B, w, row);
-            const Fe c = csr_row_dot<F, UNIT_C>(C, w, row);
-            const Fe r = fe_sub<F>(fe_mul<F>(a, b), c);
-            if (!fe_is_zero<F>(r)) {
-                ++my_bad;
-                if (row + row_offset < my_first) my_first = row + row_offset;
-            }
-            if (residuals != nullptr) fe_store(residuals + 2 * row, r);
-            if (dots != nullptr) {
-                fe_store(dots + 2 * row, a);
-                fe_store(dots + 2 * (dots_stride + row), b);
-                fe_store(dots + 2 * (2 * dots_stride + row), c);
-            }
+    if (live) {
+        const Fe r = fe_sub<F>(fe_mul<F>(a, b), c);
+        if (!fe_is_zero<F>(r)) { my_bad = 1; my_first = (u64)row + out.row_offset; }
+        if (out.residuals != nullptr) fe_store(out.residuals + 2 * (u64)row, r);
+        if (out.dots != nullptr) {
+            fe_store(out.dots + 2 * (u64)row, a);
+            fe_store(out.dots + 2 * (out.dots_stride + row), b);
+            fe_store(out.dots + 2 * (2 * out.dots_stride + row), c);
         }
     }
-    // wave reduction, then one LDS atomic per wave, one global atomic pair per block
     for (int off = 32; off > 0; off >>= 1) {
         my_bad += __shfl_down(my_bad, off, 64);
         const unsigned long long o = __shfl_down(my_first, off, 64);
         my_first = o < my_first ? o : my_first;
     }
-    if ((threadIdx.x & 63) == 0 && my_bad) {
-        atomicAdd(&s_bad, my_bad);
-        atomicMin(&s_first, my_first);
-    }
+    if ((threadIdx.x & 63) == 0 && my_bad) { atomicAdd(s_bad, my_bad); atomicMin(s_first, my_first); }
     __syncthreads();
-    if (threadIdx.x == 0 && s_bad) {
-        atomicAdd(&result[0], s_bad);
-        atomicMin(&result[1], s_first);
+    if (threadIdx.x == 0 && *s_bad) { atomicAdd(&out.result[0], *s_bad); atomicMin(&out.result[1], *s_first); }
+}
+
+// One system of a (possibly batched) launch.
+struct SellSystem {
+    SellDev A, B, C;
+    const u32* perm;       // [n_slices * 64] original row of each sorted position, kNoRow = none
+    const uint4* w;        // witness, dev format
+    u32 n_slices;
+    u32 unit_c;
+    ResidualOut out;
+};
+
+// K2: r_i = <A_i,w> * <B_i,w> - <C_i,w> for every row (verifyAssignment, src/QAP.hs:276-327, in the
+// evaluation domain).  One wave per slice, one lane per row; blockIdx.y selects the system of a
+// batched launch.  XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order),
+// so XCD x gets the contiguous tile range [x*T/8, (x+1)*T/8): the rows in flight on an XCD, and
+// the witness window they gather from, stay inside its private 4 MiB L2.  gridDim.x = tiles
+// rounded up to a multiple of 8.
+template <class F, bool UNIT_C>
+__global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
+    __shared__ unsigned long long s_bad, s_first;
+    const SellSystem& S = systems != nullptr ? systems[blockIdx.y] : one;   // batched : single
+    if (threadIdx.x == 0) { s_bad = 0; s_first = ~0ull; }
+    const u32 tiles = (S.n_slices + 3) / 4;
+    const u32 per_xcd = (tiles + 7) / 8;
+    const u32 tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= tiles) return;
+    __syncthreads();
+    const u32 slice = tile * 4 + threadIdx.x / kSlice, lane = threadIdx.x % kSlice;
+    Fe a = fe_zero(), b = a, c = a;
+    u32 row = kNoRow;
+    if (slice < S.n_slices) {
+        row = S.perm[slice * kSlice + lane];
+        a = sell_dot<F, false>(S.A, S.w, slice, lane);
+        b = sell_dot<F, false>(S.B, S.w, slice, lane);
+        c = sell_dot<F, UNIT_C>(S.C, S.w, slice, lane);
     }
+    residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out, &s_bad, &s_first);
+}
+
+// CSR path for the listed rows only (rows too long for the SELL layout).
+template <class F, bool UNIT_C>
+__global__ __launch_bounds__(kBlock) void k_r1cs_residual_rows(CsrDev A, CsrDev B, CsrDev C,
+                                                              const uint4* __restrict__ w,
+                                                              const u32* __restrict__ rows, u32 n_rows,
+                                                              ResidualOut out) {
+    __shared__ unsigned long long s_bad, s_first;
+    if (threadIdx.x == 0) { s_bad = 0; s_first = ~0ull; }
+    __syncthreads();
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n_rows;
+    Fe a = fe_zero(), b = a, c = a;
+    u32 row = kNoRow;
+    if (live) {
+        row = rows[i];
+        a = csr_row_dot<F, false>(A, w, row);
+        b = csr_row_dot<F, false>(B, w, row);
+        c = csr_row_dot<F, UNIT_C>(C, w, row);
+    }
+    residual_epilogue<F>(a, b, c, row, live, out, &s_bad, &s_first);
 }
 
 // ---------------------------------------------------------------------------------------------
