@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libacx.so")
+LIB_PATH = os.environ.get("ACX_LIB", os.path.join(HERE, "libacx.so"))   # ACX_LIB: development override
 
 ACX_OK = 0
 STATUS = {
@@ -77,15 +77,25 @@ SYMBOLS = {
     "acx_dev_to_canonical": (_I, [_P, _U64, _P, _P]),
     "acx_r1cs_verify_dev": (_I, [_P, _P, _U64, _P, _P, _P]),
     "acx_ntt_dev": (_I, [_P, _U32, _U64, _I, _P, _P]),
+    "acx_ntt_twiddle_dev": (_I, [_P, _U32, _I, _U64, _U64, _U64, _U64, _P]),
+    "acx_batch_create": (_I, [_P, _U64, _P, _P, _P, _U64, C.POINTER(_P)]),
+    "acx_batch_verify_dev": (_I, [_P]),
+    "acx_batch_destroy": (None, [_P]),
 }
 
 _lib = None
 
 
 def load() -> C.CDLL:
-    """dlopen libacx.so and declare prototypes.  Loading needs no GPU; creating a context does."""
+    """dlopen libacx.so and declare prototypes.  Loading needs no GPU; creating a context does.
+    torch is imported first so that libacx binds to the HIP runtime torch already mapped: two HIP
+    runtimes in one process cannot both own the device ("No HIP GPUs are available")."""
     global _lib
     if _lib is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:   # a host without torch uses the system ROCm runtime
+            pass
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

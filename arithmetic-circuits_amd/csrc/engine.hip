@@ -78,6 +78,15 @@ struct acx_r1cs {
     uint4* d_w = nullptr;  // witness staging, m elements
 };
 
+struct acx_batch {
+    acx_ctx* ctx = nullptr;
+    std::vector<acx_r1cs*> systems;
+    std::vector<const uint4*> witnesses;
+    std::vector<ResidualOut> outs;
+    SellSystem* d_systems = nullptr;
+    uint32_t max_slices = 0;
+};
+
 struct acx_circuit {
     HostCircuit hc;
     HostCsr rows[3];     // gateToGenQAP rows in gate order, built once
@@ -248,12 +257,8 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
     const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset};
     const SellSystem S = sell_system(r, d_w, out);
     const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
-    DISPATCH_FIELD(c, {
-        if (r->unit_c) hipLaunchKernelGGL((k_r1cs_sell<F, true>), grid, dim3(kBlock), 0, c->stream,
-                                          (const SellSystem*)nullptr, S);
-        else hipLaunchKernelGGL((k_r1cs_sell<F, false>), grid, dim3(kBlock), 0, c->stream,
-                                (const SellSystem*)nullptr, S);
-    });
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, c->stream,
+                                         (const SellSystem*)nullptr, S));
     HIP_TRY(hipGetLastError());
     return launch_long_rows(r, d_w, out);
 }
@@ -926,6 +931,79 @@ int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset,
     HIP_TRY(hipSetDevice(r->ctx->device));
     return launch_residual(r, (const uint4*)d_witness, row_offset, (unsigned long long*)d_result,
                            (uint4*)d_residuals, (uint4*)d_dots, 1ull << r->log_n);
+}
+
+int acx_ntt_twiddle_dev(acx_ctx* c, uint32_t log_n, int inverse, uint64_t rows, uint64_t cols, uint64_t row0,
+                        uint64_t col0, void* d_data) {
+    if (!c || !d_data) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
+    if (rows == 0 || cols == 0) return ACX_OK;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    H256 w = c->hf.root_of_unity((int)log_n);
+    if (inverse) w = c->hf.inv(w);
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_twiddle_tile<F>), dim3(grid_for(c, rows * cols)), dim3(kBlock), 0, c->stream,
+                                         (uint4*)d_data, rows, cols, row0, col0, dev_arg(c->hf, w)));
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int acx_batch_create(acx_ctx* ctx, uint64_t count, acx_r1cs* const* systems, const void* const* d_witnesses,
+                     uint64_t* d_results, uint64_t result_stride, acx_batch** out) {
+    if (!ctx || !systems || !d_witnesses || !d_results || !out || count == 0 || count > 65535)
+        return fail(ACX_ERR_INVALID_ARG, "bad batch arguments");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    acx_batch* b = new (std::nothrow) acx_batch();
+    if (!b) return fail(ACX_ERR_OOM, "host allocation failed");
+    b->ctx = ctx;
+    std::vector<SellSystem> host(count);
+    uint64_t row_offset = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        acx_r1cs* r = systems[i];
+        if (!r || r->ctx != ctx || !d_witnesses[i]) { delete b; return fail(ACX_ERR_INVALID_ARG, "bad batch member"); }
+        const ResidualOut o{(unsigned long long*)(d_results + i * result_stride), nullptr, nullptr, 0,
+                            result_stride ? 0 : row_offset};
+        host[i] = sell_system(r, (const uint4*)d_witnesses[i], o);
+        b->systems.push_back(r);
+        b->witnesses.push_back((const uint4*)d_witnesses[i]);
+        b->outs.push_back(o);
+        b->max_slices = std::max(b->max_slices, r->n_slices);
+        row_offset += r->n;
+    }
+    if (hipMalloc((void**)&b->d_systems, count * sizeof(SellSystem)) != hipSuccess) { delete b; return fail(ACX_ERR_OOM, "device allocation failed"); }
+    if (hipMemcpy(b->d_systems, host.data(), count * sizeof(SellSystem), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(b->d_systems); delete b; return fail(ACX_ERR_HIP, "descriptor upload failed");
+    }
+    *out = b;
+    return ACX_OK;
+}
+
+void acx_batch_destroy(acx_batch* b) {
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lock(b->ctx->mu);
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+        if (b->d_systems) (void)hipFree(b->d_systems);
+    }
+    delete b;
+}
+
+int acx_batch_verify_dev(acx_batch* b) {
+    if (!b) return fail(ACX_ERR_INVALID_ARG, "null batch");
+    acx_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (b->max_slices) {
+        const dim3 grid(sell_grid_x(b->max_slices), (unsigned)b->systems.size(), 1);
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, c->stream,
+                                             (const SellSystem*)b->d_systems, SellSystem{}));
+        HIP_TRY(hipGetLastError());
+    }
+    for (size_t i = 0; i < b->systems.size(); ++i)
+        if (b->systems[i]->n_long) ACX_TRY(launch_long_rows(b->systems[i], b->witnesses[i], b->outs[i]));
+    return ACX_OK;
 }
 
 int acx_ntt_dev(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift, void* d_data) {

@@ -190,7 +190,7 @@ struct SellSystem {
 // so XCD x gets the contiguous tile range [x*T/8, (x+1)*T/8): the rows in flight on an XCD, and
 // the witness window they gather from, stay inside its private 4 MiB L2.  gridDim.x = tiles
 // rounded up to a multiple of 8.
-template <class F, bool UNIT_C>
+template <class F>
 __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
     __shared__ unsigned long long s_bad, s_first;
     const SellSystem& S = systems != nullptr ? systems[blockIdx.y] : one;   // batched : single
@@ -198,7 +198,9 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
     const u32 tiles = (S.n_slices + 3) / 4;
     const u32 per_xcd = (tiles + 7) / 8;
     const u32 tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= tiles) return;
+    // the remap is a bijection on [0, 8*per_xcd) only: a batched launch sizes gridDim.x for its
+    // largest system, so workgroups beyond this system's own range must not run
+    if (blockIdx.x >= 8 * per_xcd || tile >= tiles) return;
     __syncthreads();
     const u32 slice = tile * 4 + threadIdx.x / kSlice, lane = threadIdx.x % kSlice;
     Fe a = fe_zero(), b = a, c = a;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
         row = S.perm[slice * kSlice + lane];
         a = sell_dot<F, false>(S.A, S.w, slice, lane);
         b = sell_dot<F, false>(S.B, S.w, slice, lane);
-        c = sell_dot<F, UNIT_C>(S.C, S.w, slice, lane);
+        c = S.unit_c ? sell_dot<F, true>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
     }
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out, &s_bad, &s_first);
 }
@@ -291,6 +293,19 @@ __global__ __launch_bounds__(kBlock) void k_scale_powers(uint4* __restrict__ dat
         Fe x = fe_mul<F>(fe_load(data + 2 * t), scale);
         if (use_base) x = fe_mul<F>(x, fe_pow<F>(base, t & (n - 1)));
         fe_store(data + 2 * t, x);
+    }
+}
+
+// Four-step twiddle: data is a rows x cols tile (row-major) of the R x C matrix of a length-N = R*C
+// transform; element (r, c) *= omega^((row0 + r) * (col0 + c)).  omega = omega_N (or its inverse).
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_twiddle_tile(uint4* __restrict__ data, u64 rows, u64 cols, u64 row0,
+                                                        u64 col0, FeArg omega_arg) {
+    const Fe omega = fe_from_arg(omega_arg);
+    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < rows * cols; t += (u64)gridDim.x * kBlock) {
+        const u64 r = t / cols, c = t - r * cols;
+        const Fe tw = fe_pow<F>(omega, (row0 + r) * (col0 + c));
+        fe_store(data + 2 * t, fe_mul<F>(fe_load(data + 2 * t), tw));
     }
 }
 

@@ -103,6 +103,11 @@ class Context:
         check(self.lib.acx_ntt_dev(self._h, log_n, batch, int(inverse), _ptr(sh), d_data))
 
 
+    def ntt_twiddle_dev(self, d_data: int, log_n: int, rows: int, cols: int, row0: int = 0, col0: int = 0,
+                        inverse: bool = False) -> None:
+        check(self.lib.acx_ntt_twiddle_dev(self._h, log_n, int(inverse), rows, cols, row0, col0, d_data))
+
+
 class R1CS:
     """acx_r1cs: a device-resident GenQAP in row (constraint) form."""
 
@@ -177,6 +182,36 @@ class R1CS:
 
     def verify_dev(self, d_witness: int, d_result: int, row_offset: int = 0, d_residuals: int = 0, d_dots: int = 0) -> None:
         check(self.ctx.lib.acx_r1cs_verify_dev(self._h, d_witness, row_offset, d_result, d_residuals or None, d_dots or None))
+
+
+class Batch:
+    """acx_batch: many (R1CS, device witness) pairs verified by one launch."""
+
+    def __init__(self, ctx: Context, systems: Sequence[R1CS], d_witnesses: Sequence[int], d_results: int,
+                 per_system: bool = False):
+        self.ctx = ctx
+        self._systems = list(systems)          # keep alive
+        n = len(self._systems)
+        hs = (C.c_void_p * n)(*[s._h for s in self._systems])
+        ws = (C.c_void_p * n)(*[int(p) for p in d_witnesses])
+        h = C.c_void_p()
+        check(ctx.lib.acx_batch_create(ctx._h, n, hs, ws, d_results, 2 if per_system else 0, C.byref(h)))
+        self._h = h
+        self.rows = sum(s.n for s in self._systems)
+
+    def verify_dev(self) -> None:
+        check(self.ctx.lib.acx_batch_verify_dev(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx.lib.acx_batch_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Circuit:

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X (contract: see the round brief).
+
+Workload (BASELINE.json configs[1]): verifyAssignment over seeded random R1CS of
+2^16 constraints each (mulgraph k=2, n_in=1024, window=4096, BN254 Fr).  One STEP = one batched
+launch that checks `--copies` (default 32) independent 2^16-constraint systems against their
+device-resident witnesses: 2^21 constraints per GPU per step, ~520 MB of constraint data per GPU
+(> the 256 MiB Infinity Cache, so the stream comes from HBM).  With N GPUs every rank holds its own
+32 systems (rows sharded with no data-path collective; N=8 is the 2^24-constraint job of
+configs[3]) and each step ends with ONE RCCL all-reduce of the violated-row count.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field)."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+acx = importlib.import_module("arithmetic-circuits_amd")
+synth = importlib.import_module("arithmetic-circuits_amd.synth")
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algorithmic_bytes(mats, n):
+    """36*nnz + 12*(n+1) + 32*m_ref + 8 per verification of one system."""
+    nnz = sum(int(m[1].shape[0]) for m in mats)
+    m_ref = int(np.unique(np.concatenate([m[1] for m in mats])).shape[0])
+    return 36 * nnz + 12 * (n + 1) + 32 * m_ref + 8, nnz, m_ref
+
+
+def to_dev(ctx, arr):
+    t = torch.from_numpy(arr.view(np.int64).copy()).cuda()
+    ctx.dev_from_canonical(arr.shape[0], t.data_ptr(), t.data_ptr())
+    return t
+
+
+def cpu_baseline(sample, budget_s=12.0):
+    """The CPU restatement (oracle/acx_oracle.c, "port") timed on this host's cores on a bounded
+    sample of the same workload: one 2^16-constraint system, repeated for ~budget_s seconds."""
+    from oracle.c_oracle import COracle
+    orc = COracle("bn254")
+    mats, w, n, m = sample
+    threads = os.cpu_count() or 1
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        _, nbad, _ = orc.r1cs_residuals(n, m, *mats, w, want_residuals=False, nthreads=threads)
+        assert nbad == 0
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s and reps >= 3:
+            break
+    return {"value": n * reps / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x verifyAssignment of one 2^{n.bit_length() - 1}-constraint system "
+                      f"(oracle/acx_oracle.c, {threads} pthreads, {dt:.1f} s)"}
+
+
+def bench_ntt(ctx, stream, log_n=20, reps=5):
+    """Secondary metric: one 2^20-point inverse NTT (= FFT.interpolate of one QAP column)."""
+    n = 1 << log_n
+    x = to_dev(ctx, synth.random_fr(n, 5, 1))
+    ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=True)
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    ops = 1.5 * n * log_n + n
+    return {"workload": f"inverse NTT N=2^{log_n} (BN254 Fr)", "us": us, "field_ops_per_s": ops / us * 1e6,
+            "algorithmic_GBps": 128 * n / us * 1e-3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--copies", type=int, default=32)
+    ap.add_argument("--logn", type=int, default=16)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = acx.Context("bn254", local_rank)
+    stream = torch.cuda.ExternalStream(ctx.stream)
+    n = 1 << a.logn
+    systems, witnesses, bytes_per_launch, nnz_total = [], [], 0, 0
+    sample = None
+    for c in range(a.copies):
+        s = synth.mulgraph(n, seed=0xAC355 + 1000 * rank + c)
+        mats = s.rows()
+        w = s.witness()
+        b, nnz, _ = algorithmic_bytes(mats, n)
+        bytes_per_launch += b
+        nnz_total += nnz
+        systems.append(s.circuit.to_r1cs(ctx))
+        witnesses.append(to_dev(ctx, w))
+        if c == 0:
+            sample = (mats, w, n, s.circuit.m)
+    ring = 8
+    init = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
+    results = [init.clone() for _ in range(ring)]
+    batches = [acx.Batch(ctx, systems, [w.data_ptr() for w in witnesses], r.data_ptr()) for r in results]
+    ctx.sync()
+    torch.cuda.synchronize()
+
+    pending = [None] * ring
+
+    def step(i):
+        b = i % ring
+        if world > 1:
+            if pending[b] is not None:
+                pending[b].wait()
+            results[b].copy_(init, non_blocking=True)
+        batches[b].verify_dev()
+        if world > 1:
+            # ONE collective per verification: sum of violated-row counts over the row shards
+            pending[b] = dist.all_reduce(results[b][:1], op=dist.ReduceOp.SUM, async_op=True)
+
+    with torch.cuda.stream(stream):
+        for i in range(a.warmup):
+            step(i)
+        for p in pending:
+            if p is not None:
+                p.wait()
+        pending = [None] * ring
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for i in range(a.steps):
+            step(i)
+        e1.record(stream)
+        for p in pending:
+            if p is not None:
+                p.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    kernel_us = e0.elapsed_time(e1) * 1e3 / a.steps
+    for r in results:
+        assert int(r[0]) == 0, "a satisfying witness was rejected"     # parity gate of the timed config
+
+    # negative control outside the timed region: one flipped witness limb must be caught
+    neg = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
+    wbad = witnesses[0].clone()
+    wbad[77, 0] ^= 1
+    systems[0].verify_dev(wbad.data_ptr(), neg.data_ptr())
+    ctx.sync()
+    assert int(neg[0]) > 0, "a corrupted witness was accepted"
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[0])
+    if rank == 0:
+        total = world * a.copies * n * a.steps
+        value = total / dt
+        achieved = bytes_per_launch / kernel_us * 1e-3   # GB/s, algorithmic bytes / launch duration
+        out = {
+            "metric": "R1CS constraints/sec (verifyAssignment, BN254 Fr, bit-exact vs oracle)",
+            "value": value, "unit": "constraints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u256 (9x29-bit limbs, Montgomery)", "data": "synthetic",
+            "config": {"workload": f"r1cs_verify: {a.copies} independent 2^{a.logn}-constraint mulgraph systems per GPU per "
+                                   f"step, one batched launch (k=2, n_in=1024, window=4096, seeds 0xAC355+1000*rank+c)",
+                       "constraints_per_step_per_gpu": a.copies * n, "nnz_per_step_per_gpu": nnz_total,
+                       "field": "bn254_fr", "parallelism": f"rows sharded x{world}, 1 all-reduce/step" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "acx::k_r1cs_sell", "kernel_us": kernel_us,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if world == 1 and not a.no_ntt:
+            out["ntt"] = bench_ntt(ctx, stream)
+        if world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

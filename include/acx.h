@@ -205,6 +205,26 @@ int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset,
 int acx_ntt_dev(acx_ctx* ctx, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift,
                 void* d_data);
 
+/* Twiddle step of a four-step / distributed NTT of length 2^log_n = R*C: the rows x cols tile at
+ * (row0, col0) of the R x C matrix is multiplied elementwise by omega_N^((row0+r)*(col0+c))
+ * (omega_N^-1 when inverse).  The RCCL all-to-all transpose between the two passes lives in the
+ * host layer (one process per GPU). */
+int acx_ntt_twiddle_dev(acx_ctx* ctx, uint32_t log_n, int inverse, uint64_t rows, uint64_t cols,
+                        uint64_t row0, uint64_t col0, void* d_data);
+
+/* Batched verification: `count` independent (constraint system, witness) pairs checked by ONE
+ * kernel launch -- the shape of the reference's property tests, `all (verifyAssignment qap .
+ * generateAssignment program) inputs` (test/Test/Circuit/Arithmetic.hs:200-209), and of a
+ * constraint system stored as independent blocks.  d_witnesses[i]: m_i dev elements.
+ * result_stride = 2: pair i accumulates into d_results[2i..2i+1] = {n_bad, first_bad};
+ * result_stride = 0: every pair accumulates into d_results[0..1], first_bad counted over the
+ * concatenation of the systems' rows.  The caller initialises d_results ({0, UINT64_MAX}). */
+typedef struct acx_batch acx_batch;
+int acx_batch_create(acx_ctx* ctx, uint64_t count, acx_r1cs* const* systems, const void* const* d_witnesses,
+                     uint64_t* d_results, uint64_t result_stride, acx_batch** out);
+int acx_batch_verify_dev(acx_batch* batch);
+void acx_batch_destroy(acx_batch* batch);
+
 #ifdef __cplusplus
 }
 #endif
