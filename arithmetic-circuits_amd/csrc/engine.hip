@@ -47,7 +47,14 @@ struct acx_ctx {
     hipStream_t stream = nullptr;
     HostField hf;
     std::mutex mu;
-    std::map<std::pair<uint32_t, int>, uint4*> twiddles;  // (log_n, inverse) -> omega^j table
+    std::map<std::pair<uint32_t, int>, uint4*> twiddles;  // (log_m, inverse) -> omega_M^j, j < M
+    std::map<std::pair<uint32_t, int>, uint4*> tw_low;    // (log_n, inverse) -> omega_N^j, j < 1024
+    uint4* ntt_scratch = nullptr;                          // ping-pong buffer of the multi-pass NTT
+    size_t ntt_scratch_bytes = 0;
+    uint4* coset_lo = nullptr;                             // g^j (j < 1024), g^(1024 j): last shift used
+    uint4* coset_hi = nullptr;
+    H256 coset_base{{0, 0, 0, 0}};
+    uint32_t coset_log_n = 0;
     unsigned long long* d_result = nullptr;                // {n_bad, first_bad}
     uint32_t* d_err = nullptr;
     int n_cu = 256;
@@ -163,53 +170,175 @@ int download_elements(acx_ctx* c, const uint4* d_in, uint64_t count, acx_fr* hos
     return ACX_OK;
 }
 
-// omega_N^j table (j < N/2), cached per (log_n, inverse).  Caller holds ctx->mu.
-int get_twiddles(acx_ctx* c, uint32_t log_n, int inverse, uint4** out) {
-    auto key = std::make_pair(log_n, inverse);
+// omega_M^j for j < M = 2^log_m (inverse: omega_M^-j), cached.  Caller holds ctx->mu.
+int get_pow_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
+    auto key = std::make_pair(log_m, inverse);
     auto it = c->twiddles.find(key);
     if (it != c->twiddles.end()) { *out = it->second; return ACX_OK; }
-    const uint64_t count = log_n ? (1ull << (log_n - 1)) : 1;
+    const uint64_t count = 1ull << log_m;
     uint4* tw = nullptr;
     HIP_TRY(hipMalloc((void**)&tw, count * 32));
-    H256 w = c->hf.root_of_unity((int)log_n);
+    H256 w = c->hf.root_of_unity((int)log_m);
     if (inverse) w = c->hf.inv(w);
-    const FeArg base = dev_arg(c->hf, w);
-    const int grid = grid_for(c, count);
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid), dim3(kBlock), 0, c->stream, tw, count, base));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, tw,
+                                         count, dev_arg(c->hf, w)));
     HIP_TRY(hipGetLastError());
     c->twiddles[key] = tw;
     *out = tw;
     return ACX_OK;
 }
 
-// In-place batched NTT on dev-format data.  Caller holds ctx->mu.
+// omega_N^j for j < 1024 (low level of the two-level twiddle table), cached.
+int get_low_table(acx_ctx* c, uint32_t log_n, int inverse, uint4** out) {
+    auto key = std::make_pair(log_n, inverse);
+    auto it = c->tw_low.find(key);
+    if (it != c->tw_low.end()) { *out = it->second; return ACX_OK; }
+    uint4* tw = nullptr;
+    HIP_TRY(hipMalloc((void**)&tw, 1024 * 32));
+    H256 w = c->hf.root_of_unity((int)log_n);
+    if (inverse) w = c->hf.inv(w);
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(4), dim3(kBlock), 0, c->stream, tw, (u64)1024,
+                                         dev_arg(c->hf, w)));
+    HIP_TRY(hipGetLastError());
+    c->tw_low[key] = tw;
+    *out = tw;
+    return ACX_OK;
+}
+
+// g^j (j < 1024) and g^(1024 j) (j < N/1024) for the coset factor; the last (g, log_n) is kept.
+int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, uint4** lo, uint4** hi) {
+    const uint64_t hi_count = log_n > 10 ? (1ull << (log_n - 10)) : 0;
+    if (!(c->coset_lo && c->coset_base == base_mont && c->coset_log_n == log_n)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));   // previous users of the old tables are done
+        if (c->coset_lo) (void)hipFree(c->coset_lo);
+        if (c->coset_hi) (void)hipFree(c->coset_hi);
+        c->coset_lo = c->coset_hi = nullptr;
+        HIP_TRY(hipMalloc((void**)&c->coset_lo, 1024 * 32));
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(4), dim3(kBlock), 0, c->stream, c->coset_lo,
+                                             (u64)1024, dev_arg(c->hf, base_mont)));
+        if (hi_count) {
+            HIP_TRY(hipMalloc((void**)&c->coset_hi, hi_count * 32));
+            const H256 b1024 = c->hf.pow_u64(base_mont, 1024);
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, hi_count)), dim3(kBlock), 0, c->stream,
+                                                 c->coset_hi, hi_count, dev_arg(c->hf, b1024)));
+        }
+        HIP_TRY(hipGetLastError());
+        c->coset_base = base_mont;
+        c->coset_log_n = log_n;
+    }
+    *lo = c->coset_lo;
+    *hi = c->coset_hi;
+    return ACX_OK;
+}
+
+inline uint64_t pow2_floor(uint64_t x) { uint64_t p = 1; while (p * 2 <= x) p *= 2; return p; }
+inline uint32_t ilog2(uint64_t x) { uint32_t k = 0; while ((1ull << (k + 1)) <= x) ++k; return k; }
+
+// In-place batched NTT on dev-format data (multi-pass tiled kernel, kernels.cuh).  Caller holds ctx->mu.
 //   forward: X[k] = sum_i x[i] (shift * omega^k)^i      inverse: undoes it.
 int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inverse, const H256* shift_mont) {
     if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
     if (batch == 0) return ACX_OK;
-    const uint64_t n = 1ull << log_n;
     const HostField& hf = c->hf;
-    if (!inverse && shift_mont) {
-        const FeArg one = dev_arg(hf, hf.one()), g = dev_arg(hf, *shift_mont);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_scale_powers<F>), dim3(grid_for(c, n * batch)), dim3(kBlock), 0,
-                                             c->stream, d, log_n, batch, one, g, 1));
+    const uint64_t N = 1ull << log_n;
+    // factor N into P digits of at most 8 bits
+    const int P = log_n <= 8 ? 1 : (int)((log_n + 7) / 8);
+    uint32_t lg[4] = {0, 0, 0, 0};
+    for (int p = 0; p < P; ++p) lg[p] = log_n / P + ((uint32_t)p < log_n % P ? 1 : 0);
+    uint64_t Wt[4], Vt[4];   // input / output weight of each digit
+    for (int p = 0; p < P; ++p) {
+        Wt[p] = 1; Vt[p] = 1;
+        for (int r = p + 1; r < P; ++r) Wt[p] <<= lg[r];
+        for (int r = 0; r < p; ++r) Vt[p] <<= lg[r];
     }
-    if (log_n > 0) {
-        uint4* tw = nullptr;
-        ACX_TRY(get_twiddles(c, log_n, inverse, &tw));
-        hipLaunchKernelGGL(k_bitrev_permute, dim3(grid_for(c, n * batch)), dim3(kBlock), 0, c->stream, d, log_n, batch);
-        for (uint32_t lh = 0; lh < log_n; ++lh) {
-            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_stage<F>), dim3(grid_for(c, (n >> 1) * batch)), dim3(kBlock), 0,
-                                                 c->stream, d, (const uint4*)tw, log_n, lh, batch));
+    uint4* scratch = nullptr;
+    if (P > 1) {
+        const size_t need = (size_t)batch * N * 32;
+        if (c->ntt_scratch_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
+            c->ntt_scratch = nullptr; c->ntt_scratch_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&c->ntt_scratch, need));
+            c->ntt_scratch_bytes = need;
         }
+        scratch = c->ntt_scratch;
     }
-    if (inverse) {
-        const H256 ninv = hf.inv(hf.from_u64(n));
-        const FeArg s = dev_arg(hf, ninv);
-        const H256 ginv = shift_mont ? hf.inv(*shift_mont) : hf.one();
-        const FeArg g = dev_arg(hf, ginv);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_scale_powers<F>), dim3(grid_for(c, n * batch)), dim3(kBlock), 0,
-                                             c->stream, d, log_n, batch, s, g, shift_mont ? 1 : 0));
+    uint4 *sc_lo = nullptr, *sc_hi = nullptr;
+    if (shift_mont) {
+        const H256 base = inverse ? hf.inv(*shift_mont) : *shift_mont;
+        ACX_TRY(get_coset_tables(c, base, log_n, &sc_lo, &sc_hi));
+    }
+    for (int p = 0; p < P; ++p) {
+        NttPass Q;
+        std::memset(&Q, 0, sizeof(Q));
+        const bool last = p == P - 1, first = p == 0;
+        Q.src = first ? d : scratch;
+        Q.dst = last ? d : scratch;
+        Q.log_s = lg[p];
+        if (lg[p] > 0) { uint4* st = nullptr; ACX_TRY(get_pow_table(c, lg[p], inverse, &st)); Q.sub_tw = st; }
+        Q.idx_mask = N - 1;
+        Q.sc_lo = sc_lo; Q.sc_hi = sc_hi;
+        const uint64_t S = 1ull << lg[p];
+        uint32_t no = 0;
+        auto add_outer = [&](uint64_t count, uint64_t sin, uint64_t sout, uint64_t kw, uint64_t iw) {
+            if (count <= 1) return;
+            Q.outer[no++] = NttOuter{(u32)count, 0, sin, sout, kw, iw};
+        };
+        uint64_t T;
+        if (P == 1) {
+            // columns = independent transforms of the batch
+            T = std::min<uint64_t>(kTileElems / S, batch & (~batch + 1));   // largest power of two dividing batch
+            Q.stride_t_in = Q.stride_t_out = 1;
+            Q.stride_c_in = Q.stride_c_out = N;
+            add_outer(batch / T, T * N, T * N, 0, 0);
+        } else if (!last) {
+            const uint64_t NP = 1ull << lg[P - 1];
+            T = std::min<uint64_t>(kTileElems / S, NP);
+            Q.stride_t_in = Q.stride_t_out = Wt[p];
+            Q.stride_c_in = Q.stride_c_out = 1;
+            Q.t_kw = Vt[p];
+            const bool next_is_last = p + 1 == P - 1;
+            Q.c_iw = next_is_last ? 1 : 0;
+            add_outer(NP / T, T, T, 0, next_is_last ? T : 0);
+            for (int q = 0; q < P - 1; ++q) {
+                if (q == p) continue;
+                add_outer(1ull << lg[q], Wt[q], Wt[q], q < p ? Vt[q] : 0, q == p + 1 ? Wt[q] : 0);
+            }
+            add_outer(batch, N, N, 0, 0);
+            // twiddle w_N^(I*K), I = i_{p+1} W_{p+1}, K = k_1 + ... + k_p V_p
+            uint32_t log_m = 0;
+            for (int r = 0; r <= p + 1; ++r) log_m += lg[r];
+            if (log_m <= 16) {
+                uint4* tw = nullptr;
+                ACX_TRY(get_pow_table(c, log_m, inverse, &tw));
+                Q.tw_mode = 1; Q.tw_lo = tw; Q.tw_shift = ilog2(Wt[p + 1]);
+            } else {
+                uint4 *lo = nullptr, *hi = nullptr;
+                ACX_TRY(get_low_table(c, log_n, inverse, &lo));
+                ACX_TRY(get_pow_table(c, log_n - 10, inverse, &hi));
+                Q.tw_mode = 2; Q.tw_lo = lo; Q.tw_hi = hi; Q.tw_mask = N - 1;
+            }
+        } else {
+            const uint64_t N1 = 1ull << lg[0];
+            T = std::min<uint64_t>(kTileElems / S, N1);
+            Q.stride_t_in = 1;            Q.stride_t_out = Vt[p];
+            Q.stride_c_in = Wt[0];        Q.stride_c_out = 1;
+            add_outer(N1 / T, T * Wt[0], T, 0, 0);
+            for (int q = 1; q < P - 1; ++q) add_outer(1ull << lg[q], Wt[q], Vt[q], 0, 0);
+            add_outer(batch, N, N, 0, 0);
+        }
+        if (no > (uint32_t)kMaxOuter) return fail(ACX_ERR_UNSUPPORTED, "NTT plan has too many dimensions");
+        Q.n_outer = no;
+        Q.log_t = ilog2(T);
+        if (first && !inverse && shift_mont) Q.scale_on_load = 1;
+        if (last) {
+            // the closing multiplication: 1 (forward), 1/N (inverse), 1/N * g^-k (inverse coset)
+            const H256 s = inverse ? hf.inv(hf.from_u64(N)) : hf.one();
+            Q.scale = dev_arg(hf, s);
+            Q.scale_mode = (inverse && shift_mont) ? 2 : 1;
+        }
+        const uint64_t tiles = batch * N / (S * T);
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_tile<F>), dim3((unsigned)tiles), dim3(kBlock), 0, c->stream, Q));
     }
     HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -547,6 +676,10 @@ void acx_ctx_destroy(acx_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
+    for (auto& kv : c->tw_low) (void)hipFree(kv.second);
+    if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
+    if (c->coset_lo) (void)hipFree(c->coset_lo);
+    if (c->coset_hi) (void)hipFree(c->coset_hi);
     if (c->d_result) (void)hipFree(c->d_result);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -565,7 +698,9 @@ int acx_ctx_set_root(acx_ctx* c, uint32_t two_adicity, const acx_fr* omega) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
+    for (auto& kv : c->tw_low) (void)hipFree(kv.second);
     c->twiddles.clear();
+    c->tw_low.clear();
     c->hf.set_omega_max(w, (int)two_adicity);
     return ACX_OK;
 }

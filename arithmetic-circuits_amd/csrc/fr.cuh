@@ -185,6 +185,41 @@ __device__ __forceinline__ Fe fe_mul(const Fe& a, const Fe& b) {
     return r;
 }
 
+// ---- lazy butterfly arithmetic (NTT) ---------------------------------------------------------------
+// "Loose" values: limbs < 2^29 + 8 (top limb free), value < 64p (fits 261 bits for both fields).
+// fe_mul accepts a loose left operand when the right operand is strictly normalised and < 2p
+// (a stored twiddle or constant): a*b/R + p < (64 p/R + 1) p <= 2p, columns stay < 2^64.
+// One parallel (non-rippling) carry pass keeps the loose invariant: 27 independent VALU ops
+// instead of the 24-deep ripple + conditional subtraction of fe_add/fe_sub (225-230 cycles each,
+// tools/microbench/fe_rates.hip).
+__device__ __forceinline__ void fe_carry_loose(Fe& a) {
+    u32 c[kLimbs - 1];
+#pragma unroll
+    for (int k = 0; k < kLimbs - 1; ++k) { c[k] = a.l[k] >> kLimbBits; a.l[k] &= kLimbMask; }
+#pragma unroll
+    for (int k = 1; k < kLimbs; ++k) a.l[k] += c[k - 1];
+}
+
+// a + b, loose in, loose out; value grows to a + b
+__device__ __forceinline__ Fe fe_add_lazy(const Fe& a, const Fe& b) {
+    Fe s;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) s.l[k] = a.l[k] + b.l[k];
+    fe_carry_loose(s);
+    return s;
+}
+
+// a - b + 4p for b strictly normalised and < 2p (a product); borrow-free thanks to the "fat"
+// limb form of 4p; value grows by at most 4p
+template <class F>
+__device__ __forceinline__ Fe fe_sub_lazy(const Fe& a, const Fe& b) {
+    Fe s;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) s.l[k] = a.l[k] + F::P4FAT[k] - b.l[k];
+    fe_carry_loose(s);
+    return s;
+}
+
 // ---- deferred reduction: sum of raw limb products, one Montgomery reduction per sum --------------
 // Column accumulators of the schoolbook product: c[k] = sum over terms of sum_{i+j=k} a_i b_j.
 // Each v_mad_u64_u32 adds straight into its column (no carry handling at all).  With limbs

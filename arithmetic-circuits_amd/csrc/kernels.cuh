@@ -238,8 +238,6 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_residual_rows(CsrDev A, CsrDev 
 
 // ---------------------------------------------------------------------------------------------
 // NTT (replaces galois-fft `FFT.fft` / `FFT.interpolate`; call sites src/QAP.hs:521-524).
-// v1: bit-reversal permutation + one radix-2 DIT stage per launch, twiddles from a table
-// tw[j] = omega_N^j (j < N/2).  Batched: `batch` contiguous transforms of length 2^log_n.
 
 // tw[j] = base^j for j < count
 template <class F>
@@ -249,50 +247,131 @@ __global__ __launch_bounds__(kBlock) void k_pow_table(uint4* __restrict__ tw, u6
         fe_store(tw + 2 * j, fe_pow<F>(base, j));
 }
 
-__global__ __launch_bounds__(kBlock) void k_bitrev_permute(uint4* __restrict__ data, u32 log_n, u64 batch) {
-    const u64 n = 1ull << log_n;
-    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < n * batch; t += (u64)gridDim.x * kBlock) {
-        const u64 b = t >> log_n;
-        const u32 i = (u32)(t & (n - 1));
-        const u32 j = log_n ? (__brev(i) >> (32 - log_n)) : 0;
-        if (j > i) {
-            uint4* x = data + 2 * ((b << log_n) + i);
-            uint4* y = data + 2 * ((b << log_n) + j);
-            const uint4 x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
-            x[0] = y0; x[1] = y1; y[0] = x0; y[1] = x1;
+// ---- K3/K4: tiled multi-pass NTT ---------------------------------------------------------------
+// A length-N transform is factored N = N_1 * ... * N_P (P <= 4, every N_p <= 256).  Pass p runs
+// all the length-N_p sub-transforms over digit p of the index; a workgroup owns a tile of
+// S = N_p points x T columns (S*T = 1024 elements, 36 KiB of LDS in limb-plane form, so four
+// workgroups share a CU and one tile's global load/store overlaps the others' butterflies).
+// T consecutive elements of the fastest-varying remaining digit form a 32*T-byte segment: every
+// global access is a full 128/256-byte line.  Inside the tile: bit-reversed placement on load,
+// log2(S) radix-2 DIT stages out of LDS with lazy (carry-only) add/sub, then ONE multiplication
+// per element that both applies the inter-pass twiddle w_N^(I*K) (or the final 1/N, coset factor)
+// and brings the lazily grown value back below 2p.  The last pass stores in natural order, so
+// there is no separate transpose or bit-reversal kernel and no barrier between workgroups.
+constexpr int kTileElems = 1024;
+constexpr int kMaxOuter = 4;
+
+struct NttOuter {          // one outer loop dimension of the tile enumeration
+    u32 count;             // number of values
+    u32 pad;
+    u64 stride_in, stride_out;   // element strides
+    u64 k_w, i_w;          // contribution of this index to the twiddle factors K and I
+};
+
+struct NttPass {
+    const uint4* src;
+    uint4* dst;
+    const uint4* sub_tw;   // w_S^j, j < S/2 (dev format, strictly normalised)
+    const uint4* tw_lo;    // twiddle table: direct (w_M^e, e < M) or low level of a two-level table
+    const uint4* tw_hi;    // high level (w^(1024 j)) or null
+    const uint4* sc_lo;    // coset powers g^j (j < 1024) or null
+    const uint4* sc_hi;    // g^(1024 j) or null
+    u32 log_s, log_t;      // S points, T columns
+    u32 n_outer;
+    u32 tw_mode;           // 0 none, 1 direct table index (I*K) >> tw_shift, 2 two-level on (I*K) & tw_mask
+    u32 tw_shift;
+    u32 scale_mode;        // 0 none, 1 multiply by `scale`, 2 scale * g^(element index) via sc_lo/sc_hi
+    u32 scale_on_load;     // coset pre-multiplication of a forward transform (first pass)
+    u32 pad;
+    u64 tw_mask;
+    u64 stride_t_in, stride_t_out;   // transform direction
+    u64 stride_c_in, stride_c_out;   // column direction
+    u64 t_kw;              // K contribution of the output digit k_p
+    u64 c_kw, c_iw;        // K / I contribution of the column index
+    u64 idx_mask;          // element index within its transform = offset & idx_mask (coset exponent)
+    NttOuter outer[kMaxOuter];
+    FeArg scale;
+};
+
+template <class F>
+__device__ __forceinline__ Fe two_level_pow(const uint4* __restrict__ lo, const uint4* __restrict__ hi, u64 e) {
+    const Fe a = fe_load(lo + 2 * (e & 1023));
+    if (hi == nullptr) return a;
+    return fe_mul<F>(a, fe_load(hi + 2 * (e >> 10)));
+}
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_ntt_tile(NttPass P) {
+    __shared__ u32 lds[kLimbs][kTileElems];
+    const u32 S = 1u << P.log_s, T = 1u << P.log_t, elems = S * T;
+    // tile -> outer indices
+    u64 base_in = 0, base_out = 0, K0 = 0, I0 = 0;
+    {
+        u64 t = blockIdx.x;
+        for (u32 d = 0; d < P.n_outer; ++d) {
+            const u64 idx = t % P.outer[d].count;
+            t /= P.outer[d].count;
+            base_in += idx * P.outer[d].stride_in;
+            base_out += idx * P.outer[d].stride_out;
+            K0 += idx * P.outer[d].k_w;
+            I0 += idx * P.outer[d].i_w;
         }
     }
-}
-
-// one DIT stage: butterflies (i0, i0 + half) with twiddle tw[j * (N / (2 half))]
-template <class F>
-__global__ __launch_bounds__(kBlock) void k_ntt_stage(uint4* __restrict__ data, const uint4* __restrict__ tw,
-                                                     u32 log_n, u32 log_half, u64 batch) {
-    const u64 n = 1ull << log_n, half = 1ull << log_half;
-    const u64 total = (n >> 1) * batch;
-    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < total; t += (u64)gridDim.x * kBlock) {
-        const u64 b = t >> (log_n - 1);
-        const u64 bf = t & ((n >> 1) - 1);
-        const u64 j = bf & (half - 1), grp = bf >> log_half;
-        const u64 i0 = (b << log_n) + (grp << (log_half + 1)) + j, i1 = i0 + half;
-        const Fe u = fe_load(data + 2 * i0);
-        const Fe v = fe_load(data + 2 * i1);
-        const Fe wv = fe_mul<F>(v, fe_load(tw + 2 * (j << (log_n - 1 - log_half))));
-        fe_store(data + 2 * i0, fe_add<F>(u, wv));
-        fe_store(data + 2 * i1, fe_sub<F>(u, wv));
+    // load: element (point d, column c), placed at bit-reversed point position
+    for (u32 e = threadIdx.x; e < elems; e += kBlock) {
+        const u32 c = e & (T - 1), d = e >> P.log_t;
+        const u64 off = base_in + (u64)d * P.stride_t_in + (u64)c * P.stride_c_in;
+        Fe x = fe_load(P.src + 2 * off);
+        if (P.scale_on_load) x = fe_mul<F>(x, two_level_pow<F>(P.sc_lo, P.sc_hi, off & P.idx_mask));
+        const u32 pos = ((P.log_s ? (__brev(d) >> (32 - P.log_s)) : 0u) << P.log_t) | c;
+#pragma unroll
+        for (int k = 0; k < kLimbs; ++k) lds[k][pos] = x.l[k];
     }
-}
-
-// x[i] *= scale * base^i   (coset shift before a forward transform; N^-1 * g^-i after an inverse)
-template <class F>
-__global__ __launch_bounds__(kBlock) void k_scale_powers(uint4* __restrict__ data, u32 log_n, u64 batch,
-                                                        FeArg scale_arg, FeArg base_arg, int use_base) {
-    const Fe scale = fe_from_arg(scale_arg), base = fe_from_arg(base_arg);
-    const u64 n = 1ull << log_n;
-    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < n * batch; t += (u64)gridDim.x * kBlock) {
-        Fe x = fe_mul<F>(fe_load(data + 2 * t), scale);
-        if (use_base) x = fe_mul<F>(x, fe_pow<F>(base, t & (n - 1)));
-        fe_store(data + 2 * t, x);
+    __syncthreads();
+    // radix-2 DIT stages
+    for (u32 lh = 0; lh < P.log_s; ++lh) {
+        const u32 h = 1u << lh;
+        for (u32 b = threadIdx.x; b < elems / 2; b += kBlock) {
+            const u32 c = b & (T - 1), q = b >> P.log_t;
+            const u32 j = q & (h - 1), grp = q >> lh;
+            const u32 i0 = (((grp << (lh + 1)) + j) << P.log_t) | c, i1 = i0 + (h << P.log_t);
+            Fe u, v;
+#pragma unroll
+            for (int k = 0; k < kLimbs; ++k) { u.l[k] = lds[k][i0]; v.l[k] = lds[k][i1]; }
+            Fe t;
+            if (lh == 0) {
+                // w_2^0 = 1: no multiplication, but v must become a strict product-like value < 2p:
+                // after load every value is strict and < 2p, so it already is.
+                t = v;
+            } else {
+                t = fe_mul<F>(v, fe_load(P.sub_tw + 2 * (u64)(j << (P.log_s - 1 - lh))));
+            }
+            const Fe a = fe_add_lazy(u, t), s = fe_sub_lazy<F>(u, t);
+#pragma unroll
+            for (int k = 0; k < kLimbs; ++k) { lds[k][i0] = a.l[k]; lds[k][i1] = s.l[k]; }
+        }
+        __syncthreads();
+    }
+    // store with the reducing multiplication
+    const Fe scale = fe_from_arg(P.scale);
+    for (u32 e = threadIdx.x; e < elems; e += kBlock) {
+        const u32 c = e & (T - 1), d = e >> P.log_t;      // d = output digit k_p
+        Fe x;
+#pragma unroll
+        for (int k = 0; k < kLimbs; ++k) x.l[k] = lds[k][e];
+        const u64 off = base_out + (u64)d * P.stride_t_out + (u64)c * P.stride_c_out;
+        Fe f;
+        if (P.tw_mode != 0) {
+            const u64 K = K0 + (u64)d * P.t_kw + (u64)c * P.c_kw, I = I0 + (u64)c * P.c_iw;
+            const u64 E = I * K;
+            f = (P.tw_mode == 1) ? fe_load(P.tw_lo + 2 * (E >> P.tw_shift))
+                                 : two_level_pow<F>(P.tw_lo, P.tw_hi, E & P.tw_mask);
+        } else if (P.scale_mode == 2) {
+            f = fe_mul<F>(scale, two_level_pow<F>(P.sc_lo, P.sc_hi, off & P.idx_mask));
+        } else {
+            f = scale;
+        }
+        fe_store(P.dst + 2 * off, fe_mul<F>(x, f));
     }
 }
 
