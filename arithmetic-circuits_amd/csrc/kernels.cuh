@@ -32,6 +32,22 @@ __global__ __launch_bounds__(kBlock) void k_convert(const uint4* __restrict__ in
     }
 }
 
+// Witness staging: canonical (checked, -> Montgomery) or dev format -> 48-byte limb format
+// (fr.cuh "expanded storage"): the residual kernels gather witness entries ~6 times per row from
+// L2, so the 29-bit limb split is done once here instead of at every gather.
+template <class F, bool FROM_CANONICAL>
+__global__ __launch_bounds__(kBlock) void k_witness_expand(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                          u64 count, u32* __restrict__ err) {
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < count; i += (u64)gridDim.x * kBlock) {
+        Fe x = fe_load(in + 2 * i);
+        if (FROM_CANONICAL) {
+            if (err != nullptr && !fe_lt_p<F>(x)) atomicOr(err, 1u);
+            x = fe_to_mont<F>(x);
+        }
+        fe_store_limbs(out + 3 * i, x);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2: R1CS residual check = `verifyAssignment` (/root/reference/src/QAP.hs:276-327) in the
 // evaluation domain: r_i = <A_i,w> * <B_i,w> - <C_i,w> for every constraint row i.
@@ -47,7 +63,7 @@ __device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restri
     Fe acc = fe_zero();
     if (UNIT) {
         for (u32 e = e0; e < e1; ++e) {
-            const Fe x = fe_load(w + 2 * (u64)M.col[e]);
+            const Fe x = fe_load_limbs(w + 3 * (u64)M.col[e]);
             acc = (e == e0) ? x : fe_add<F>(acc, x);
         }
         return acc;
@@ -58,7 +74,7 @@ __device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restri
         wide_zero(wide);
         for (u32 e = base; e < end; ++e) {
             const Fe v = fe_load(M.val + 2 * (u64)e);
-            const Fe x = fe_load(w + 2 * (u64)M.col[e]);
+            const Fe x = fe_load_limbs(w + 3 * (u64)M.col[e]);
             wide_mac(wide, v, x);
         }
         const Fe part = wide_reduce<F>(wide);
@@ -84,14 +100,16 @@ constexpr u32 kNoRow = 0xffffffffu;
 
 struct SellDev {
     const u32* slice_ofs;  // [n_slices + 1] slot offsets
-    const u32* col;        // [slots * 64]; kNoRow marks padding
-    const uint4* val;      // [slots * 2 * 64]: slot q, half h, lane l at (2q + h) * 64 + l
+    const uint2* tail;     // [slots * 64]: { limb 8 of the value, column }; column kNoRow marks padding
+    const uint4* val;      // [slots * 2 * 64]: limbs 0-3 / 4-7 of slot q, lane l at (2q + h) * 64 + l
 };
 
-// Gather one matrix from its (device, dev-format) CSR into the SELL arrays.
+// Gather one matrix from its (device, dev-format) CSR into the SELL arrays.  Values are stored as
+// 29-bit limbs (40 bytes per entry with the column index instead of 36): the residual kernel is
+// bound by integer VALU issue, not by HBM, and this removes the limb split from its inner loop.
 __global__ __launch_bounds__(kBlock) void k_build_sell(CsrDev M, const u32* __restrict__ perm,
                                                       const u32* __restrict__ slice_ofs, u32 n_slices,
-                                                      u32* __restrict__ col, uint4* __restrict__ val) {
+                                                      uint2* __restrict__ tail, uint4* __restrict__ val) {
     const u32 slice = blockIdx.x * (kBlock / kSlice) + (threadIdx.x / kSlice);
     const u32 lane = threadIdx.x % kSlice;
     if (slice >= n_slices) return;
@@ -101,12 +119,12 @@ __global__ __launch_bounds__(kBlock) void k_build_sell(CsrDev M, const u32* __re
     if (row != kNoRow) { e0 = M.rowptr[row]; len = M.rowptr[row + 1] - e0; }
     for (u32 q = q0; q < q1; ++q) {
         const u32 j = q - q0;
-        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        Fe v = fe_zero();
         u32 c = kNoRow;
-        if (j < len) { lo = M.val[2 * (u64)(e0 + j)]; hi = M.val[2 * (u64)(e0 + j) + 1]; c = M.col[e0 + j]; }
-        col[(u64)q * kSlice + lane] = c;
-        val[(2 * (u64)q) * kSlice + lane] = lo;
-        val[(2 * (u64)q + 1) * kSlice + lane] = hi;
+        if (j < len) { v = fe_load(M.val + 2 * (u64)(e0 + j)); c = M.col[e0 + j]; }
+        tail[(u64)q * kSlice + lane] = make_uint2(v.l[8], c);
+        val[(2 * (u64)q) * kSlice + lane] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        val[(2 * (u64)q + 1) * kSlice + lane] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
     }
 }
 
@@ -116,8 +134,11 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
     Fe acc = fe_zero();
     if (UNIT) {
         for (u32 q = q0; q < q1; ++q) {
-            const u32 c = M.col[(u64)q * kSlice + lane];
-            if (c != kNoRow) acc = fe_add<F>(acc, fe_load(w + 2 * (u64)c));
+            const u32 c = M.tail[(u64)q * kSlice + lane].y;
+            if (c != kNoRow) {
+                const Fe x = fe_load_limbs(w + 3 * (u64)c);
+                acc = (q == q0) ? x : fe_add<F>(acc, x);    // rows are sorted: padding never precedes data
+            }
         }
         return acc;
     }
@@ -125,13 +146,15 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
     for (u32 base = q0; base < q1; base += kWideTerms) {
         const u32 end = (q1 - base > (u32)kWideTerms) ? base + kWideTerms : q1;
         Wide wide;
-        wide_zero(wide);
         for (u32 q = base; q < end; ++q) {
-            const u32 c = M.col[(u64)q * kSlice + lane];
+            const uint2 t = M.tail[(u64)q * kSlice + lane];
             const uint4 lo = M.val[(2 * (u64)q) * kSlice + lane], hi = M.val[(2 * (u64)q + 1) * kSlice + lane];
-            const u32 vw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            const Fe x = fe_load(w + 2 * (u64)(c == kNoRow ? 0u : c));   // padding: value 0 * w[0]
-            wide_mac(wide, fe_unpack(vw), x);
+            Fe v;
+            v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
+            v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
+            v.l[8] = t.x;
+            const Fe x = fe_load_limbs(w + 3 * (u64)(t.y == kNoRow ? 0u : t.y));   // padding: value 0 * w[0]
+            if (q == base) wide_mul(wide, v, x); else wide_mac(wide, v, x);
         }
         const Fe part = wide_reduce<F>(wide);
         acc = have ? fe_add<F>(acc, part) : part;
@@ -148,15 +171,15 @@ struct ResidualOut {
     u64 row_offset;
 };
 
-// per-lane epilogue shared by the SELL and the CSR-rows kernels
+// per-lane epilogue shared by the SELL and the CSR-rows kernels.  Violations are the rare case: a
+// wave without any skips the reduction entirely (one ballot); otherwise one atomic pair per wave.
 template <class F>
 __device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, const Fe& c, u32 row, bool live,
-                                                  const ResidualOut& out, unsigned long long* s_bad,
-                                                  unsigned long long* s_first) {
-    unsigned long long my_bad = 0, my_first = ~0ull;
+                                                  const ResidualOut& out) {
+    bool bad = false;
     if (live) {
         const Fe r = fe_sub<F>(fe_mul<F>(a, b), c);
-        if (!fe_is_zero<F>(r)) { my_bad = 1; my_first = (u64)row + out.row_offset; }
+        bad = !fe_is_zero<F>(r);
         if (out.residuals != nullptr) fe_store(out.residuals + 2 * (u64)row, r);
         if (out.dots != nullptr) {
             fe_store(out.dots + 2 * (u64)row, a);
@@ -164,21 +187,24 @@ __device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, cons
             fe_store(out.dots + 2 * (2 * out.dots_stride + row), c);
         }
     }
+    const unsigned long long mask = __ballot(bad);
+    if (mask == 0) return;                                   // wave-uniform
+    unsigned long long my_first = bad ? (u64)row + out.row_offset : ~0ull;
     for (int off = 32; off > 0; off >>= 1) {
-        my_bad += __shfl_down(my_bad, off, 64);
         const unsigned long long o = __shfl_down(my_first, off, 64);
         my_first = o < my_first ? o : my_first;
     }
-    if ((threadIdx.x & 63) == 0 && my_bad) { atomicAdd(s_bad, my_bad); atomicMin(s_first, my_first); }
-    __syncthreads();
-    if (threadIdx.x == 0 && *s_bad) { atomicAdd(&out.result[0], *s_bad); atomicMin(&out.result[1], *s_first); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out.result[0], (unsigned long long)__popcll(mask));
+        atomicMin(&out.result[1], my_first);
+    }
 }
 
 // One system of a (possibly batched) launch.
 struct SellSystem {
     SellDev A, B, C;
     const u32* perm;       // [n_slices * 64] original row of each sorted position, kNoRow = none
-    const uint4* w;        // witness, dev format
+    const uint4* w;        // witness, 48-byte limb format (k_witness_expand)
     u32 n_slices;
     u32 unit_c;
     ResidualOut out;
@@ -191,17 +217,14 @@ struct SellSystem {
 // the witness window they gather from, stay inside its private 4 MiB L2.  gridDim.x = tiles
 // rounded up to a multiple of 8.
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
-    __shared__ unsigned long long s_bad, s_first;
+__global__ __launch_bounds__(kBlock, 5) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
     const SellSystem& S = systems != nullptr ? systems[blockIdx.y] : one;   // batched : single
-    if (threadIdx.x == 0) { s_bad = 0; s_first = ~0ull; }
     const u32 tiles = (S.n_slices + 3) / 4;
     const u32 per_xcd = (tiles + 7) / 8;
     const u32 tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     // the remap is a bijection on [0, 8*per_xcd) only: a batched launch sizes gridDim.x for its
     // largest system, so workgroups beyond this system's own range must not run
     if (blockIdx.x >= 8 * per_xcd || tile >= tiles) return;
-    __syncthreads();
     const u32 slice = tile * 4 + threadIdx.x / kSlice, lane = threadIdx.x % kSlice;
     Fe a = fe_zero(), b = a, c = a;
     u32 row = kNoRow;
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
         b = sell_dot<F, false>(S.B, S.w, slice, lane);
         c = S.unit_c ? sell_dot<F, true>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
     }
-    residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out, &s_bad, &s_first);
+    residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
 }
 
 // CSR path for the listed rows only (rows too long for the SELL layout).
@@ -220,9 +243,6 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_residual_rows(CsrDev A, CsrDev 
                                                               const uint4* __restrict__ w,
                                                               const u32* __restrict__ rows, u32 n_rows,
                                                               ResidualOut out) {
-    __shared__ unsigned long long s_bad, s_first;
-    if (threadIdx.x == 0) { s_bad = 0; s_first = ~0ull; }
-    __syncthreads();
     const u32 i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < n_rows;
     Fe a = fe_zero(), b = a, c = a;
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_residual_rows(CsrDev A, CsrDev 
         b = csr_row_dot<F, false>(B, w, row);
         c = csr_row_dot<F, UNIT_C>(C, w, row);
     }
-    residual_epilogue<F>(a, b, c, row, live, out, &s_bad, &s_first);
+    residual_epilogue<F>(a, b, c, row, live, out);
 }
 
 // ---------------------------------------------------------------------------------------------
