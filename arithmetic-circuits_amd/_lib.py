@@ -75,8 +75,6 @@ SYMBOLS = {
     "acx_ntt": (_I, [_P, _U32, _U64, _I, _P, _P, _P]),
     "acx_dev_from_canonical": (_I, [_P, _U64, _P, _P, _P]),
     "acx_dev_to_canonical": (_I, [_P, _U64, _P, _P]),
-    "acx_witness_from_canonical_dev": (_I, [_P, _U64, _P, _P, _P]),
-    "acx_witness_from_dev": (_I, [_P, _U64, _P, _P]),
     "acx_r1cs_verify_dev": (_I, [_P, _P, _U64, _P, _P, _P]),
     "acx_ntt_dev": (_I, [_P, _U32, _U64, _I, _P, _P]),
     "acx_ntt_twiddle_dev": (_I, [_P, _U32, _I, _U64, _U64, _U64, _U64, _P]),

@@ -82,7 +82,7 @@ struct acx_r1cs {
     u32* long_rows = nullptr;
     uint32_t n_slices = 0, n_long = 0;
     bool has_csc = false;
-    uint4* d_w = nullptr;  // witness staging, m elements in the 48-byte limb format
+    uint4* d_w = nullptr;  // witness staging, m elements
 };
 
 struct acx_batch {
@@ -155,35 +155,6 @@ int upload_elements(acx_ctx* c, const acx_fr* host, uint64_t count, uint4* d_out
     HIP_TRY(hipMemsetAsync(c->d_err, 0, 4, c->stream));
     HIP_TRY(hipMemcpyAsync(d_out, host, count * 32, hipMemcpyHostToDevice, c->stream));
     ACX_TRY(launch_convert(c, true, d_out, d_out, count, c->d_err));
-    uint32_t err = 0;
-    HIP_TRY(hipMemcpyAsync(&err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (err) return fail(ACX_ERR_NONCANONICAL, "element >= p");
-    return ACX_OK;
-}
-
-int launch_witness_expand(acx_ctx* c, bool from_canonical, const void* in, void* out, uint64_t count, uint32_t* d_err) {
-    if (count == 0) return ACX_OK;
-    const int grid = grid_for(c, count);
-    DISPATCH_FIELD(c, {
-        if (from_canonical) hipLaunchKernelGGL((k_witness_expand<F, true>), dim3(grid), dim3(kBlock), 0, c->stream,
-                                               (const uint4*)in, (uint4*)out, count, d_err);
-        else hipLaunchKernelGGL((k_witness_expand<F, false>), dim3(grid), dim3(kBlock), 0, c->stream,
-                                (const uint4*)in, (uint4*)out, count, d_err);
-    });
-    HIP_TRY(hipGetLastError());
-    return ACX_OK;
-}
-
-// Upload a canonical host witness into the 48-byte limb format.  d_out holds count*(48+32) bytes:
-// the raw 32-byte elements are staged BEHIND the expanded area (the strides differ, so an in-place
-// expansion would race).
-int upload_witness(acx_ctx* c, const acx_fr* host, uint64_t count, uint4* d_out) {
-    if (count == 0) return ACX_OK;
-    uint4* stage = d_out + 3 * count;
-    HIP_TRY(hipMemsetAsync(c->d_err, 0, 4, c->stream));
-    HIP_TRY(hipMemcpyAsync(stage, host, count * 32, hipMemcpyHostToDevice, c->stream));
-    ACX_TRY(launch_witness_expand(c, true, stage, d_out, count, c->d_err));
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(&err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -606,7 +577,7 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
     }
     if (rc == ACX_OK) rc = build_sell(r, rowptrs);
     if (rc == ACX_OK) {
-        hipError_t e = hipMalloc((void**)&r->d_w, m * 80);
+        hipError_t e = hipMalloc((void**)&r->d_w, m * 32);
         if (e != hipSuccess) rc = fail(ACX_ERR_OOM, "witness buffer allocation failed");
     }
     if (rc != ACX_OK) {
@@ -919,7 +890,7 @@ int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* c
 static int verify_common(acx_r1cs* r, const acx_fr* witness, uint64_t* n_bad, uint64_t* first_bad, uint4* d_res,
                          uint4* d_dots, uint64_t dots_stride) {
     acx_ctx* c = r->ctx;
-    ACX_TRY(upload_witness(c, witness, r->m, r->d_w));
+    ACX_TRY(upload_elements(c, witness, r->m, r->d_w));
     const unsigned long long init[2] = {0ull, ~0ull};
     HIP_TRY(hipMemcpyAsync(c->d_result, init, 16, hipMemcpyHostToDevice, c->stream));
     ACX_TRY(launch_residual(r, r->d_w, 0, c->d_result, d_res, d_dots, dots_stride));
@@ -1086,20 +1057,6 @@ int acx_dev_to_canonical(acx_ctx* c, uint64_t count, const void* d_in, void* d_o
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     return launch_convert(c, false, d_in, d_out, count, nullptr);
-}
-
-int acx_witness_from_canonical_dev(acx_ctx* c, uint64_t count, const void* d_in, void* d_out, uint32_t* d_err) {
-    if (!c || !d_in || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lock(c->mu);
-    HIP_TRY(hipSetDevice(c->device));
-    return launch_witness_expand(c, true, d_in, d_out, count, d_err);
-}
-
-int acx_witness_from_dev(acx_ctx* c, uint64_t count, const void* d_in, void* d_out) {
-    if (!c || !d_in || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lock(c->mu);
-    HIP_TRY(hipSetDevice(c->device));
-    return launch_witness_expand(c, false, d_in, d_out, count, nullptr);
 }
 
 int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset, uint64_t* d_result,

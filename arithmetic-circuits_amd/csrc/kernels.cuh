@@ -32,22 +32,6 @@ __global__ __launch_bounds__(kBlock) void k_convert(const uint4* __restrict__ in
     }
 }
 
-// Witness staging: canonical (checked, -> Montgomery) or dev format -> 48-byte limb format
-// (fr.cuh "expanded storage"): the residual kernels gather witness entries ~6 times per row from
-// L2, so the 29-bit limb split is done once here instead of at every gather.
-template <class F, bool FROM_CANONICAL>
-__global__ __launch_bounds__(kBlock) void k_witness_expand(const uint4* __restrict__ in, uint4* __restrict__ out,
-                                                          u64 count, u32* __restrict__ err) {
-    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < count; i += (u64)gridDim.x * kBlock) {
-        Fe x = fe_load(in + 2 * i);
-        if (FROM_CANONICAL) {
-            if (err != nullptr && !fe_lt_p<F>(x)) atomicOr(err, 1u);
-            x = fe_to_mont<F>(x);
-        }
-        fe_store_limbs(out + 3 * i, x);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // K2: R1CS residual check = `verifyAssignment` (/root/reference/src/QAP.hs:276-327) in the
 // evaluation domain: r_i = <A_i,w> * <B_i,w> - <C_i,w> for every constraint row i.
@@ -63,7 +47,7 @@ __device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restri
     Fe acc = fe_zero();
     if (UNIT) {
         for (u32 e = e0; e < e1; ++e) {
-            const Fe x = fe_load_limbs(w + 3 * (u64)M.col[e]);
+            const Fe x = fe_load(w + 2 * (u64)M.col[e]);
             acc = (e == e0) ? x : fe_add<F>(acc, x);
         }
         return acc;
@@ -74,7 +58,7 @@ __device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restri
         wide_zero(wide);
         for (u32 e = base; e < end; ++e) {
             const Fe v = fe_load(M.val + 2 * (u64)e);
-            const Fe x = fe_load_limbs(w + 3 * (u64)M.col[e]);
+            const Fe x = fe_load(w + 2 * (u64)M.col[e]);
             wide_mac(wide, v, x);
         }
         const Fe part = wide_reduce<F>(wide);
@@ -136,29 +120,49 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
         for (u32 q = q0; q < q1; ++q) {
             const u32 c = M.tail[(u64)q * kSlice + lane].y;
             if (c != kNoRow) {
-                const Fe x = fe_load_limbs(w + 3 * (u64)c);
+                const Fe x = fe_load(w + 2 * (u64)c);
                 acc = (q == q0) ? x : fe_add<F>(acc, x);    // rows are sorted: padding never precedes data
             }
         }
         return acc;
     }
+    // Software pipeline, one slot deep.  Ablation on 2^22 rows (profiles/r01_r1cs_ablation.txt):
+    // removing the multiplies saves 4 us of 345, removing the witness gathers 140, removing the
+    // value stream 95 -- the kernel is bound by memory latency x concurrency (a divergent gather
+    // costs one L1 tag lookup per lane), not by VALU or HBM bytes.  So: the gather of slot q is
+    // issued first, then the stream loads of slot q+1, and only the gather is waited for (vmcnt
+    // retires in order), which keeps a value-stream request in flight during every multiply.
     bool have = false;
-    for (u32 base = q0; base < q1; base += kWideTerms) {
-        const u32 end = (q1 - base > (u32)kWideTerms) ? base + kWideTerms : q1;
-        Wide wide;
-        for (u32 q = base; q < end; ++q) {
-            const uint2 t = M.tail[(u64)q * kSlice + lane];
-            const uint4 lo = M.val[(2 * (u64)q) * kSlice + lane], hi = M.val[(2 * (u64)q + 1) * kSlice + lane];
-            Fe v;
-            v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
-            v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
-            v.l[8] = t.x;
-            const Fe x = fe_load_limbs(w + 3 * (u64)(t.y == kNoRow ? 0u : t.y));   // padding: value 0 * w[0]
-            if (q == base) wide_mul(wide, v, x); else wide_mac(wide, v, x);
+    int terms = 0;
+    Wide wide;
+    uint2 t = make_uint2(0, kNoRow);
+    uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+    if (q0 < q1) {
+        t = M.tail[(u64)q0 * kSlice + lane];
+        lo = M.val[(2 * (u64)q0) * kSlice + lane];
+        hi = M.val[(2 * (u64)q0 + 1) * kSlice + lane];
+    }
+    for (u32 q = q0; q < q1; ++q) {
+        const uint4* px = w + 2 * (u64)(t.y == kNoRow ? 0u : t.y);   // padding: value 0 * w[0]
+        const uint4 xlo = px[0], xhi = px[1];
+        Fe v;
+        v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
+        v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
+        v.l[8] = t.x;
+        if (q + 1 < q1) {
+            t = M.tail[(u64)(q + 1) * kSlice + lane];
+            lo = M.val[(2 * (u64)(q + 1)) * kSlice + lane];
+            hi = M.val[(2 * (u64)(q + 1) + 1) * kSlice + lane];
         }
-        const Fe part = wide_reduce<F>(wide);
-        acc = have ? fe_add<F>(acc, part) : part;
-        have = true;
+        const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
+        const Fe x = fe_unpack(xw);
+        if (terms == 0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
+        if (++terms == kWideTerms || q + 1 == q1) {
+            const Fe part = wide_reduce<F>(wide);
+            acc = have ? fe_add<F>(acc, part) : part;
+            have = true;
+            terms = 0;
+        }
     }
     return acc;
 }
@@ -204,7 +208,7 @@ __device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, cons
 struct SellSystem {
     SellDev A, B, C;
     const u32* perm;       // [n_slices * 64] original row of each sorted position, kNoRow = none
-    const uint4* w;        // witness, 48-byte limb format (k_witness_expand)
+    const uint4* w;        // witness, dev format (32 bytes per element)
     u32 n_slices;
     u32 unit_c;
     ResidualOut out;
@@ -217,7 +221,7 @@ struct SellSystem {
 // the witness window they gather from, stay inside its private 4 MiB L2.  gridDim.x = tiles
 // rounded up to a multiple of 8.
 template <class F>
-__global__ __launch_bounds__(kBlock, 5) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
+__global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
     const SellSystem& S = systems != nullptr ? systems[blockIdx.y] : one;   // batched : single
     const u32 tiles = (S.n_slices + 3) / 4;
     const u32 per_xcd = (tiles + 7) / 8;

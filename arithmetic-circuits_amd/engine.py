@@ -98,13 +98,6 @@ class Context:
     def dev_to_canonical(self, count: int, d_in: int, d_out: int) -> None:
         check(self.lib.acx_dev_to_canonical(self._h, count, d_in, d_out))
 
-    def witness_from_canonical_dev(self, count: int, d_in: int, d_out48: int, d_err: int = 0) -> None:
-        """canonical 32-byte elements -> 48-byte witness device format (what verify_dev gathers)."""
-        check(self.lib.acx_witness_from_canonical_dev(self._h, count, d_in, d_out48, d_err or None))
-
-    def witness_from_dev(self, count: int, d_in: int, d_out48: int) -> None:
-        check(self.lib.acx_witness_from_dev(self._h, count, d_in, d_out48))
-
     def ntt_dev(self, d_data: int, log_n: int, batch: int = 1, inverse: bool = False, shift: Optional[int] = None) -> None:
         sh = ints_to_fr([shift]) if shift is not None else None
         check(self.lib.acx_ntt_dev(self._h, log_n, batch, int(inverse), _ptr(sh), d_data))

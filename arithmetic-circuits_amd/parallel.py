@@ -87,10 +87,9 @@ class ShardedR1CS:
         else:
             ctx = self.ctx
             dev = f"cuda:{ctx.device}"
-            wc = torch.from_numpy(np.ascontiguousarray(witness, dtype=np.uint64).view(np.int64)).to(dev)
-            w = torch.empty((self.m, 6), dtype=torch.int64, device=dev)
+            w = torch.from_numpy(np.ascontiguousarray(witness, dtype=np.uint64).view(np.int64)).to(dev)
             torch.cuda.synchronize()
-            ctx.witness_from_canonical_dev(self.m, wc.data_ptr(), w.data_ptr())
+            ctx.dev_from_canonical(self.m, w.data_ptr(), w.data_ptr())
             stream = torch.cuda.ExternalStream(ctx.stream)
             with torch.cuda.stream(stream):
                 self._res.copy_(torch.tensor([0, -1], dtype=torch.int64), non_blocking=False)

@@ -35,16 +35,6 @@ def algorithmic_bytes(mats, n):
     return 36 * nnz + 12 * (n + 1) + 32 * m_ref + 8, nnz, m_ref
 
 
-def to_wdev(ctx, arr):
-    """canonical host elements -> device witness format (48 B/element)"""
-    t = torch.from_numpy(arr.view(np.int64).copy()).cuda()
-    out = torch.empty((arr.shape[0], 6), dtype=torch.int64, device="cuda")
-    torch.cuda.synchronize()
-    ctx.witness_from_canonical_dev(arr.shape[0], t.data_ptr(), out.data_ptr())
-    ctx.sync()
-    return out
-
-
 def to_dev(ctx, arr):
     t = torch.from_numpy(arr.view(np.int64).copy()).cuda()
     torch.cuda.synchronize()
@@ -126,7 +116,7 @@ def main():
         bytes_per_launch += b
         nnz_total += nnz
         systems.append(s.circuit.to_r1cs(ctx))
-        witnesses.append(to_wdev(ctx, w))
+        witnesses.append(to_dev(ctx, w))
         if c == 0:
             sample = (mats, w, n, s.circuit.m)
     ring = 8

@@ -196,13 +196,7 @@ int acx_ntt(acx_ctx* ctx, uint32_t log_n, uint64_t batch, int inverse, const acx
  * GPU) that keep data resident between collectives, and by bench.py. */
 int acx_dev_from_canonical(acx_ctx* ctx, uint64_t count, const void* d_in, void* d_out, uint32_t* d_err);
 int acx_dev_to_canonical(acx_ctx* ctx, uint64_t count, const void* d_in, void* d_out);
-/* Witness device format ("wdev"): 48 bytes per element (the value's nine 29-bit limbs), produced
- * from canonical or dev elements by the two functions below; the residual kernels gather each
- * witness entry several times and read it without any unpacking. */
-int acx_witness_from_canonical_dev(acx_ctx* ctx, uint64_t count, const void* d_in, void* d_out48,
-                                   uint32_t* d_err);
-int acx_witness_from_dev(acx_ctx* ctx, uint64_t count, const void* d_in, void* d_out48);
-/* d_witness: m wdev elements.  d_result: 2 x uint64 {n_bad, first_bad}, accumulated with
+/* d_witness: m dev elements.  d_result: 2 x uint64 {n_bad, first_bad}, accumulated with
  * atomicAdd / atomicMin so that several shards can target one buffer; caller initialises it to
  * {0, UINT64_MAX}.  row_offset is added to the local row index for first_bad.
  * d_residuals (n dev elements) and d_dots (3*N dev elements: <A,w>,<B,w>,<C,w>) may be NULL. */
@@ -221,7 +215,7 @@ int acx_ntt_twiddle_dev(acx_ctx* ctx, uint32_t log_n, int inverse, uint64_t rows
 /* Batched verification: `count` independent (constraint system, witness) pairs checked by ONE
  * kernel launch -- the shape of the reference's property tests, `all (verifyAssignment qap .
  * generateAssignment program) inputs` (test/Test/Circuit/Arithmetic.hs:200-209), and of a
- * constraint system stored as independent blocks.  d_witnesses[i]: m_i wdev elements.
+ * constraint system stored as independent blocks.  d_witnesses[i]: m_i dev elements.
  * result_stride = 2: pair i accumulates into d_results[2i..2i+1] = {n_bad, first_bad};
  * result_stride = 0: every pair accumulates into d_results[0..1], first_bad counted over the
  * concatenation of the systems' rows.  The caller initialises d_results ({0, UINT64_MAX}). */

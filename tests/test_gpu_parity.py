@@ -301,10 +301,9 @@ def test_batch_verify_matches_single(request, acx):
             w[5 + c, 0] ^= np.uint64(1)
         r = s.circuit.to_r1cs(ctx)
         want.append(r.verify(w))
-        tc = torch.from_numpy(w.view(np.int64).copy()).cuda()
-        t = torch.empty((w.shape[0], 6), dtype=torch.int64, device="cuda")
+        t = torch.from_numpy(w.view(np.int64).copy()).cuda()
         torch.cuda.synchronize()
-        ctx.witness_from_canonical_dev(w.shape[0], tc.data_ptr(), t.data_ptr())
+        ctx.dev_from_canonical(w.shape[0], t.data_ptr(), t.data_ptr())
         ctx.sync()
         systems.append(r)
         wit.append(t)

@@ -35,16 +35,6 @@ def time_stream(stream, fn, reps, warmup=3):
     return e0.elapsed_time(e1) * 1e3 / reps   # us
 
 
-def to_wdev(ctx, arr):
-    """canonical host elements -> device witness format (48 B/element)"""
-    t = torch.from_numpy(arr.view(np.int64).copy()).cuda()
-    out = torch.empty((arr.shape[0], 6), dtype=torch.int64, device="cuda")
-    torch.cuda.synchronize()
-    ctx.witness_from_canonical_dev(arr.shape[0], t.data_ptr(), out.data_ptr())
-    ctx.sync()
-    return out
-
-
 def to_dev(ctx, arr):
     t = torch.from_numpy(arr.view(np.int64).copy()).cuda()
     torch.cuda.synchronize()
@@ -60,7 +50,7 @@ def bench_r1cs(ctx, stream, log_n, reps, copies):
         s = synth.mulgraph(n, seed=0xAC355 + c)
         mats = s.rows()
         r = s.circuit.to_r1cs(ctx)
-        w = to_wdev(ctx, s.witness())
+        w = to_dev(ctx, s.witness())
         systems.append((r, w, mats))
     b, nnz, m_ref = alg_bytes(systems[0][2], n)
     res = torch.zeros(2, dtype=torch.int64, device="cuda")
