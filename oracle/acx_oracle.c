@@ -201,10 +201,12 @@ static void parallel_for(size_t n, int nthreads, range_fn fn, void *ctx) {
 /* ------------------------------------------------------------------ R1CS */
 typedef struct {
     const uint32_t *rowptr; const uint32_t *col; const uint64_t *val; /* val: nnz x 4, canonical */
+    const fe *val_mont;  /* optional: the same values already in Montgomery form */
 } orc_csr;
 
 typedef struct {
     const orc_field *F; size_t n, m; orc_csr M[3]; const fe *w_mont;
+    int repeat;        /* baseline timing only: evaluate every row this many times */
     fe *dots[3];       /* optional outputs, Montgomery */
     uint64_t *res_out; /* optional residuals canonical, n x 4 */
     uint64_t *bad_count; uint64_t *first_bad; /* per thread */
@@ -213,8 +215,9 @@ typedef struct {
 static void csr_dot(const orc_field *F, const orc_csr *M, const fe *w, size_t row, fe *acc) {
     fe a = {{0, 0, 0, 0}};
     for (uint32_t e = M->rowptr[row]; e < M->rowptr[row + 1]; ++e) {
-        fe c, t; memcpy(&c, M->val + 4 * (size_t)e, 32);
-        fe_to_mont(F, &c, &c);
+        fe c, t;
+        if (M->val_mont) c = M->val_mont[e];
+        else { memcpy(&c, M->val + 4 * (size_t)e, 32); fe_to_mont(F, &c, &c); }
         fe_mul(F, &t, &c, &w[M->col[e]]);
         fe_add(F, &a, &a, &t);
     }
@@ -223,6 +226,8 @@ static void csr_dot(const orc_field *F, const orc_csr *M, const fe *w, size_t ro
 static void r1cs_range(void *vctx, size_t lo, size_t hi, int tid) {
     r1cs_job *J = vctx; const orc_field *F = J->F;
     uint64_t bad = 0, first = UINT64_MAX;
+    for (int rep = 0; rep < (J->repeat > 1 ? J->repeat : 1); ++rep) {
+    bad = 0; first = UINT64_MAX;
     for (size_t i = lo; i < hi; ++i) {
         fe a, b, c, r;
         csr_dot(F, &J->M[0], J->w_mont, i, &a);
@@ -232,6 +237,7 @@ static void r1cs_range(void *vctx, size_t lo, size_t hi, int tid) {
         fe_mul(F, &r, &a, &b); fe_sub(F, &r, &r, &c);
         if (!fe_is_zero(&r)) { bad++; if (first == UINT64_MAX) first = i; }
         if (J->res_out) { fe_from_mont(F, &r, &r); memcpy(J->res_out + 4 * i, &r, 32); }
+    }
     }
     J->bad_count[tid] = bad; J->first_bad[tid] = first;
 }
@@ -249,11 +255,20 @@ int orc_r1cs_residuals(const orc_field *F, uint64_t n, uint64_t m,
                        const uint32_t *b_rowptr, const uint32_t *b_col, const uint64_t *b_val,
                        const uint32_t *c_rowptr, const uint32_t *c_col, const uint64_t *c_val,
                        const uint64_t *witness, uint64_t *residuals,
-                       uint64_t *n_bad, uint64_t *first_bad, int nthreads) {
+                       uint64_t *n_bad, uint64_t *first_bad, int nthreads, int repeat) {
     if (nthreads < 1) nthreads = 1;
     fe *wm = witness_to_mont(F, witness, m);
-    r1cs_job J = {F, n, m, {{a_rowptr, a_col, a_val}, {b_rowptr, b_col, b_val}, {c_rowptr, c_col, c_val}},
-                  wm, {0, 0, 0}, residuals, calloc(nthreads, 8), calloc(nthreads, 8)};
+    r1cs_job J = {F, n, m, {{a_rowptr, a_col, a_val, 0}, {b_rowptr, b_col, b_val, 0}, {c_rowptr, c_col, c_val, 0}},
+                  wm, repeat, {0, 0, 0}, residuals, calloc(nthreads, 8), calloc(nthreads, 8)};
+    fe *vm[3] = {0, 0, 0};
+    if (repeat > 1) {   /* baseline timing: convert the coefficients once, like the GPU engine does at load */
+        for (int k = 0; k < 3; ++k) {
+            size_t nnz = J.M[k].rowptr[n];
+            vm[k] = malloc(sizeof(fe) * (nnz ? nnz : 1));
+            for (size_t e = 0; e < nnz; ++e) { fe t; memcpy(&t, J.M[k].val + 4 * e, 32); fe_to_mont(F, &vm[k][e], &t); }
+            J.M[k].val_mont = vm[k];
+        }
+    }
     for (int t = 0; t < nthreads; ++t) J.first_bad[t] = UINT64_MAX;
     parallel_for(n, nthreads, r1cs_range, &J);
     uint64_t bad = 0, first = UINT64_MAX;
@@ -261,6 +276,7 @@ int orc_r1cs_residuals(const orc_field *F, uint64_t n, uint64_t m,
     if (n_bad) *n_bad = bad;
     if (first_bad) *first_bad = first;
     free(J.bad_count); free(J.first_bad); free(wm);
+    for (int k = 0; k < 3; ++k) free(vm[k]);
     return 0;
 }
 
@@ -367,8 +383,8 @@ int orc_qap_h(const orc_field *F, uint64_t n, uint64_t m, int log_n,
     if (nthreads < 1) nthreads = 1;
     fe *wm = witness_to_mont(F, witness, m);
     fe *d[3]; for (int k = 0; k < 3; ++k) d[k] = calloc(N + 1, sizeof(fe));
-    r1cs_job J = {F, n, m, {{a_rowptr, a_col, a_val}, {b_rowptr, b_col, b_val}, {c_rowptr, c_col, c_val}},
-                  wm, {d[0], d[1], d[2]}, 0, calloc(nthreads, 8), calloc(nthreads, 8)};
+    r1cs_job J = {F, n, m, {{a_rowptr, a_col, a_val, 0}, {b_rowptr, b_col, b_val, 0}, {c_rowptr, c_col, c_val, 0}},
+                  wm, 1, {d[0], d[1], d[2]}, 0, calloc(nthreads, 8), calloc(nthreads, 8)};
     parallel_for(n, nthreads, r1cs_range, &J);
     uint64_t bad = 0; for (int t = 0; t < nthreads; ++t) bad += J.bad_count[t];
     *ok = (bad == 0);

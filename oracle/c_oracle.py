@@ -92,7 +92,7 @@ class COracle:
         return (rowptr, col, val), [_p(rowptr, C.c_uint32), _p(col, C.c_uint32), _p(val, C.c_uint64)]
 
     def r1cs_residuals(self, n: int, m: int, A, B, Cm, witness: np.ndarray, want_residuals: bool = True,
-                       nthreads: int = 1) -> Tuple[Optional[np.ndarray], int, int]:
+                       nthreads: int = 1, repeat: int = 1) -> Tuple[Optional[np.ndarray], int, int]:
         keep, args = [], []
         for M in (A, B, Cm):
             k, a = self._csr_args(M)
@@ -103,7 +103,7 @@ class COracle:
         res = np.zeros((n, 4), dtype=np.uint64) if want_residuals else None
         nbad, first = C.c_uint64(0), C.c_uint64(0)
         rc = self.lib.orc_r1cs_residuals(self._F, C.c_uint64(n), C.c_uint64(m), *args, _p(w, C.c_uint64),
-                                         _p(res, C.c_uint64), C.byref(nbad), C.byref(first), C.c_int(nthreads))
+                                         _p(res, C.c_uint64), C.byref(nbad), C.byref(first), C.c_int(nthreads), C.c_int(repeat))
         assert rc == 0
         return res, nbad.value, first.value
 
