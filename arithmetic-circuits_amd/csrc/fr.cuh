@@ -88,8 +88,14 @@ __device__ __forceinline__ void fe_pack(const Fe& a, u32 w[8]) {
     }
 }
 
+// Every element buffer lives in global memory.  Pinning the address space and the vector type gives
+// exactly two global_load/store_dwordx4 per element; with generic pointers hipcc emitted flat
+// accesses (for pointers reached through a descriptor) and re-split the 32 bytes into 4+16+12.
+typedef u32 v4u32 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) v4u32 g_v4u32_t;
+
 __device__ __forceinline__ Fe fe_load(const uint4* __restrict__ p) {
-    const uint4 lo = p[0], hi = p[1];
+    const v4u32 lo = *(const g_v4u32_t*)p, hi = *(const g_v4u32_t*)(p + 1);
     const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return fe_unpack(w);
 }
@@ -97,8 +103,11 @@ __device__ __forceinline__ Fe fe_load(const uint4* __restrict__ p) {
 __device__ __forceinline__ void fe_store(uint4* __restrict__ p, const Fe& a) {
     u32 w[8];
     fe_pack(a, w);
-    p[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    v4u32 lo, hi;
+    lo.x = w[0]; lo.y = w[1]; lo.z = w[2]; lo.w = w[3];
+    hi.x = w[4]; hi.y = w[5]; hi.z = w[6]; hi.w = w[7];
+    *(g_v4u32_t*)p = lo;
+    *(g_v4u32_t*)(p + 1) = hi;
 }
 
 // ---- expanded ("limb") storage: 48 bytes per element, no unpacking on load -----------------------
@@ -219,23 +228,26 @@ __device__ __forceinline__ void fe_carry_loose(Fe& a) {
     for (int k = 1; k < kLimbs; ++k) a.l[k] += c[k - 1];
 }
 
-// a + b, loose in, loose out; value grows to a + b
+// a + b, loose in, loose out; value grows to a + b.  CARRY = false skips the carry pass: limbs may
+// then reach 2^30 + 16, which the next (carrying) add/sub and fe_mul's left operand tolerate
+// (9 * 2^31.4 * 2^29 + 9 * 2^58 < 2^64); used on every other butterfly stage.
+template <bool CARRY = true>
 __device__ __forceinline__ Fe fe_add_lazy(const Fe& a, const Fe& b) {
     Fe s;
 #pragma unroll
     for (int k = 0; k < kLimbs; ++k) s.l[k] = a.l[k] + b.l[k];
-    fe_carry_loose(s);
+    if (CARRY) fe_carry_loose(s);
     return s;
 }
 
 // a - b + 4p for b strictly normalised and < 2p (a product); borrow-free thanks to the "fat"
 // limb form of 4p; value grows by at most 4p
-template <class F>
+template <class F, bool CARRY = true>
 __device__ __forceinline__ Fe fe_sub_lazy(const Fe& a, const Fe& b) {
     Fe s;
 #pragma unroll
     for (int k = 0; k < kLimbs; ++k) s.l[k] = a.l[k] + F::P4FAT[k] - b.l[k];
-    fe_carry_loose(s);
+    if (CARRY) fe_carry_loose(s);
     return s;
 }
 

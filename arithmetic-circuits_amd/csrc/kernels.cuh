@@ -112,15 +112,51 @@ __global__ __launch_bounds__(kBlock) void k_build_sell(CsrDev M, const u32* __re
     }
 }
 
+// Pointers that reach a kernel through a descriptor in memory (SellSystem) have no known address
+// space and hipcc emits flat_load for them (counted against lgkmcnt as well as vmcnt, and split into
+// odd 4/16/12-byte pieces for the 32-byte gathers).  These helpers pin the global address space
+// and the access width: one global_load_dwordx4 / dwordx2 per call.
+typedef __attribute__((address_space(1))) const uint4 g_uint4;
+typedef __attribute__((address_space(1))) const uint2 g_uint2;
+typedef __attribute__((address_space(1))) const u32 g_u32;
+typedef u32 v2u32 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const v4u32 g_v4u32;
+typedef __attribute__((address_space(1))) const v2u32 g_v2u32;
+
+__device__ __forceinline__ uint4 gload(const uint4* p) {
+    const v4u32 r = *(g_v4u32*)p;
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ uint2 gload(const uint2* p) {
+    const v2u32 r = *(g_v2u32*)p;
+    return make_uint2(r.x, r.y);
+}
+__device__ __forceinline__ u32 gload(const u32* p) { return *(g_u32*)p; }
+// The constraint stream is read exactly once per verification: non-temporal loads keep it from
+// evicting the witness window (re-read by every row) out of the XCD's L2.
+__device__ __forceinline__ uint4 nt_load(const uint4* p) {
+    const v4u32 r = __builtin_nontemporal_load((g_v4u32*)p);
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ uint2 nt_load(const uint2* p) {
+    const v2u32 r = __builtin_nontemporal_load((g_v2u32*)p);
+    return make_uint2(r.x, r.y);
+}
+__device__ __forceinline__ Fe fe_gload(const uint4* p) {
+    const uint4 lo = gload(p), hi = gload(p + 1);
+    const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return fe_unpack(w);
+}
+
 template <class F, bool UNIT>
 __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane) {
-    const u32 q0 = M.slice_ofs[slice], q1 = M.slice_ofs[slice + 1];   // wave-uniform
+    const u32 q0 = gload(M.slice_ofs + slice), q1 = gload(M.slice_ofs + slice + 1);   // wave-uniform
     Fe acc = fe_zero();
     if (UNIT) {
         for (u32 q = q0; q < q1; ++q) {
-            const u32 c = M.tail[(u64)q * kSlice + lane].y;
+            const u32 c = gload(&M.tail[(u64)q * kSlice + lane]).y;
             if (c != kNoRow) {
-                const Fe x = fe_load(w + 2 * (u64)c);
+                const Fe x = fe_gload(w + 2 * (u64)c);
                 acc = (q == q0) ? x : fe_add<F>(acc, x);    // rows are sorted: padding never precedes data
             }
         }
@@ -138,21 +174,21 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
     uint2 t = make_uint2(0, kNoRow);
     uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
     if (q0 < q1) {
-        t = M.tail[(u64)q0 * kSlice + lane];
-        lo = M.val[(2 * (u64)q0) * kSlice + lane];
-        hi = M.val[(2 * (u64)q0 + 1) * kSlice + lane];
+        t = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
+        lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
+        hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
     }
     for (u32 q = q0; q < q1; ++q) {
         const uint4* px = w + 2 * (u64)(t.y == kNoRow ? 0u : t.y);   // padding: value 0 * w[0]
-        const uint4 xlo = px[0], xhi = px[1];
+        const uint4 xlo = gload(px), xhi = gload(px + 1);
         Fe v;
         v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
         v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
         v.l[8] = t.x;
         if (q + 1 < q1) {
-            t = M.tail[(u64)(q + 1) * kSlice + lane];
-            lo = M.val[(2 * (u64)(q + 1)) * kSlice + lane];
-            hi = M.val[(2 * (u64)(q + 1) + 1) * kSlice + lane];
+            t = nt_load(&M.tail[(u64)(q + 1) * kSlice + lane]);
+            lo = nt_load(&M.val[(2 * (u64)(q + 1)) * kSlice + lane]);
+            hi = nt_load(&M.val[(2 * (u64)(q + 1) + 1) * kSlice + lane]);
         }
         const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
         const Fe x = fe_unpack(xw);
@@ -233,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
     Fe a = fe_zero(), b = a, c = a;
     u32 row = kNoRow;
     if (slice < S.n_slices) {
-        row = S.perm[slice * kSlice + lane];
+        row = gload(S.perm + slice * kSlice + lane);
         a = sell_dot<F, false>(S.A, S.w, slice, lane);
         b = sell_dot<F, false>(S.B, S.w, slice, lane);
         c = S.unit_c ? sell_dot<F, true>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);

@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--copies", type=int, default=32)
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--field", default="bn254", choices=["bn254", "bls12_381"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the collective code path even with one rank (RCCL smoke test on a 1-GPU box)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     a = ap.parse_args()
@@ -103,9 +105,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ctx = acx.Context(a.field, local_rank)
     stream = torch.cuda.ExternalStream(ctx.stream)
@@ -134,12 +139,12 @@ def main():
 
     def step(i):
         b = i % ring
-        if world > 1:
+        if use_dist:
             if pending[b] is not None:
                 pending[b].wait()
             results[b].copy_(init, non_blocking=True)
         batches[b].verify_dev()
-        if world > 1:
+        if use_dist:
             # ONE collective per verification: sum of violated-row counts over the row shards
             pending[b] = dist.all_reduce(results[b][:1], op=dist.ReduceOp.SUM, async_op=True)
 
@@ -150,7 +155,7 @@ def main():
             if p is not None:
                 p.wait()
         pending = [None] * ring
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -163,7 +168,7 @@ def main():
             if p is not None:
                 p.wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
     kernel_us = e0.elapsed_time(e1) * 1e3 / a.steps
@@ -178,7 +183,7 @@ def main():
     ctx.sync()
     assert int(neg[0]) > 0, "a corrupted witness was accepted"
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
@@ -194,7 +199,7 @@ def main():
             "config": {"workload": f"r1cs_verify: {a.copies} independent 2^{a.logn}-constraint mulgraph systems per GPU per "
                                    f"step, one batched launch (k=2, n_in=1024, window=4096, seeds 0xAC355+1000*rank+c)",
                        "constraints_per_step_per_gpu": a.copies * n, "nnz_per_step_per_gpu": nnz_total,
-                       "field": a.field + "_fr", "parallelism": f"rows sharded x{world}, 1 all-reduce/step" if world > 1 else "single GPU"},
+                       "field": a.field + "_fr", "parallelism": f"rows sharded x{world}, 1 all-reduce/step" if use_dist else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "acx::k_r1cs_sell", "kernel_us": kernel_us,
@@ -205,7 +210,7 @@ def main():
         if world == 1 and not a.no_cpu and a.field == "bn254":
             out["cpu_baseline"] = cpu_baseline(sample)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
