@@ -357,3 +357,48 @@ def test_hip_ops_distributed_layer_world1(request, acx):
     w[100, 0] ^= np.uint64(1)
     r = s.circuit.to_r1cs(ctx)
     assert sh.verify(w) == r.verify(w)
+
+
+# ------------------------------------------------------------------ generic constraint matrices (no circuit structure)
+@pytest.mark.parametrize("field,seed", [("bn254", 1), ("bn254", 2), ("bls12_381", 3)])
+def test_generic_random_csr_vs_oracle(request, acx, field, seed):
+    """acx_r1cs_load on arbitrary sparse matrices: empty rows, rows of 1..40 entries (the SELL
+    layout's 6-term reduction chunks, its 8-entry cut-over to the CSR path for long rows), zero
+    and maximal values, a NON-unit C matrix, n not a multiple of 64 -- residuals, flags, h(x) and
+    per-wire polynomials bit-equal to the oracle."""
+    ctx, orc = _ctx(request, field), _orc(request, field)
+    p = ctx.p
+    rs = np.random.RandomState(100 + seed)
+    rnd = random.Random(200 + seed)
+    n, m = 1000 + 37 * seed, 300
+    mats = []
+    for k in range(3):
+        lens = rs.choice([0, 1, 2, 3, 5, 6, 7, 8, 9, 13, 40], size=n, p=[.05, .2, .25, .2, .1, .05, .05, .04, .03, .02, .01])
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        col = np.concatenate([np.sort(rs.choice(m, size=l, replace=False)) for l in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.uint32)
+        special = [0, 1, p - 1, p - 2, (p + 1) // 2]
+        vals = [rnd.choice(special) if rnd.random() < 0.15 else rnd.randrange(p) for _ in range(int(rowptr[-1]))]
+        mats.append((rowptr, col, acx.ints_to_fr(vals)))
+    w = acx.ints_to_fr([1] + [rnd.randrange(p) for _ in range(m - 1)])
+    r = acx.R1CS.load(ctx, n, m, *mats)
+    want, nbad, first = orc.r1cs_residuals(n, m, *mats, w, nthreads=8)
+    assert np.array_equal(r.residuals(w), want)
+    assert r.verify(w) == (nbad == 0, nbad, first) and nbad > 0
+    h, ok = r.qap_h(w)
+    assert ok is False and h is None
+    for k in range(3):
+        cols, lens = r.qap_columns(k, 5, 7)
+        assert np.array_equal(cols, orc.qap_columns(n, r.log_n, mats[k], 5, 7, nthreads=8))
+    # a satisfiable instance on the same A, B: C := diag-free "row i -> wire i" with the right value
+    # is not expressible in general, so check the zero-knowledge identity instead on a tiny system
+    # built to be satisfied: rows A_i = e_1, B_i = e_2, C_i = e_3 with w3 = w1 * w2
+    one = acx.ints_to_fr([1])
+    rp = np.arange(0, 65 + 1, dtype=np.uint32)
+    mk = lambda c: (rp, np.full(65, c, dtype=np.uint32), np.repeat(one, 65, axis=0))
+    a, b = rnd.randrange(p), rnd.randrange(p)
+    w2 = acx.ints_to_fr([1, a, b, a * b % p])
+    r2 = acx.R1CS.load(ctx, 65, 4, mk(1), mk(2), mk(3))
+    d = [rnd.randrange(p) for _ in range(3)]
+    h2, ok2 = r2.qap_h(w2, d)
+    want_h, want_ok = orc.qap_h(65, 4, r2.log_n, mk(1), mk(2), mk(3), w2, delta=d)
+    assert ok2 and want_ok and acx.fr_to_ints(h2) == R.to_poly(limbs_to_ints(want_h), p)
