@@ -72,6 +72,11 @@ SYMBOLS = {
     "acx_r1cs_residuals": (_I, [_P, _P, _P]),
     "acx_qap_h": (_I, [_P, _P, _P, _P, C.POINTER(_U64), C.POINTER(_I)]),
     "acx_qap_columns": (_I, [_P, _I, _U64, _U64, _P, _P]),
+    "acx_naive_create": (_I, [_P, _P, _U64, C.POINTER(_P)]),
+    "acx_naive_destroy": (None, [_P]),
+    "acx_naive_target": (_I, [_P, _P]),
+    "acx_naive_columns": (_I, [_P, _I, _U64, _U64, _P, _P]),
+    "acx_naive_h": (_I, [_P, _P, _P, _P, C.POINTER(_U64), C.POINTER(_I)]),
     "acx_ntt": (_I, [_P, _U32, _U64, _I, _P, _P, _P]),
     "acx_dev_from_canonical": (_I, [_P, _U64, _P, _P, _P]),
     "acx_dev_to_canonical": (_I, [_P, _U64, _P, _P]),

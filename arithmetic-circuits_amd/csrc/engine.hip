@@ -94,6 +94,15 @@ struct acx_batch {
     uint32_t max_slices = 0;
 };
 
+struct acx_naive {          // createPolynomials state for arbitrary distinct roots (n <= 4096)
+    acx_r1cs* r = nullptr;
+    uint32_t n = 0;
+    uint4* roots = nullptr;  // [n] dev
+    uint4* tcoef = nullptr;  // [n + 1] target polynomial, dev
+    uint4* winv = nullptr;   // [n]
+    uint4* Q = nullptr;      // [n][n]
+};
+
 struct acx_circuit {
     HostCircuit hc;
     HostCsr rows[3];     // gateToGenQAP rows in gate order, built once
@@ -1080,6 +1089,173 @@ int acx_ntt_twiddle_dev(acx_ctx* c, uint32_t log_n, int inverse, uint64_t rows, 
     DISPATCH_FIELD(c, hipLaunchKernelGGL((k_twiddle_tile<F>), dim3(grid_for(c, rows * cols)), dim3(kBlock), 0, c->stream,
                                          (uint4*)d_data, rows, cols, row0, col0, dev_arg(c->hf, w)));
     HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+// ---------------------------------------------------------------------------------- naive-roots path
+void acx_naive_destroy(acx_naive* nv) {
+    if (!nv) return;
+    {
+        std::lock_guard<std::mutex> lock(nv->r->ctx->mu);
+        (void)hipSetDevice(nv->r->ctx->device);
+        (void)hipStreamSynchronize(nv->r->ctx->stream);
+        if (nv->roots) (void)hipFree(nv->roots);
+        if (nv->tcoef) (void)hipFree(nv->tcoef);
+        if (nv->winv) (void)hipFree(nv->winv);
+        if (nv->Q) (void)hipFree(nv->Q);
+    }
+    delete nv;
+}
+
+int acx_naive_create(acx_r1cs* r, const acx_fr* roots, uint64_t n_roots, acx_naive** out) {
+    if (!r || !roots || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (n_roots != r->n) return fail(ACX_ERR_ROOT_COUNT, "one root per constraint row is required");
+    if (r->n == 0 || r->n > 4096) return fail(ACX_ERR_TOO_LARGE, "naive interpolation supports 1..4096 rows");
+    acx_ctx* c = r->ctx;
+    const HostField& hf = c->hf;
+    for (uint64_t i = 0; i < n_roots; ++i) {
+        H256 a, b;
+        std::memcpy(a.l, roots[i].b, 32);
+        if (!hf.is_canonical(a)) return fail(ACX_ERR_NONCANONICAL, "root >= p");
+        if (i) {
+            std::memcpy(b.l, roots[i - 1].b, 32);
+            if (h256_cmp(b, a) >= 0) return fail(ACX_ERR_DUPLICATE_ROOT, "roots must be distinct and ascending (row order)");
+        }
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    acx_naive* nv = new (std::nothrow) acx_naive();
+    if (!nv) return fail(ACX_ERR_OOM, "host allocation failed");
+    nv->r = r;
+    const uint32_t n = (uint32_t)r->n;
+    nv->n = n;
+    DevBuf tmp;
+    int rc = tmp.alloc((size_t)(n + 1) * 32);
+    auto bail = [&](int code) { if (nv->roots) (void)hipFree(nv->roots); if (nv->tcoef) (void)hipFree(nv->tcoef);
+                                if (nv->winv) (void)hipFree(nv->winv); if (nv->Q) (void)hipFree(nv->Q); delete nv; return code; };
+    if (rc != ACX_OK) return bail(rc);
+    if (hipMalloc((void**)&nv->roots, (size_t)n * 32) != hipSuccess || hipMalloc((void**)&nv->tcoef, (size_t)(n + 1) * 32) != hipSuccess ||
+        hipMalloc((void**)&nv->winv, (size_t)n * 32) != hipSuccess || hipMalloc((void**)&nv->Q, (size_t)n * n * 32) != hipSuccess)
+        return bail(fail(ACX_ERR_OOM, "device allocation failed"));
+    rc = upload_elements(c, roots, n, nv->roots);
+    if (rc != ACX_OK) return bail(rc);
+    Exp256 pm2;
+    {
+        H256 e = hf.modulus();
+        e.l[0] -= 2;   // p is odd and > 2: no borrow
+        for (int i = 0; i < 8; ++i) pm2.w[i] = (u32)(e.l[i / 2] >> (32 * (i % 2)));
+    }
+    DISPATCH_FIELD(c, {
+        hipLaunchKernelGGL((k_poly_from_roots<F>), dim3(1), dim3(1024), 0, c->stream, (const uint4*)nv->roots, n, nv->tcoef, tmp.as<uint4>());
+        hipLaunchKernelGGL((k_bary_inv<F>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const uint4*)nv->roots, n, nv->winv, pm2);
+        hipLaunchKernelGGL((k_build_q<F>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const uint4*)nv->roots,
+                           (const uint4*)nv->tcoef, (const uint4*)nv->winv, n, nv->Q);
+    });
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(ACX_ERR_HIP, "naive setup kernels failed"));
+    *out = nv;
+    return ACX_OK;
+}
+
+int acx_naive_target(acx_naive* nv, acx_fr* out) {
+    if (!nv || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    acx_ctx* c = nv->r->ctx;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf tmp;
+    ACX_TRY(tmp.alloc((size_t)(nv->n + 1) * 32));
+    return download_elements(c, nv->tcoef, nv->n + 1, out, tmp.as<uint4>());
+}
+
+int acx_naive_columns(acx_naive* nv, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out,
+                      uint64_t* out_len) {
+    if (!nv || matrix < 0 || matrix > 2 || !out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    acx_r1cs* r = nv->r;
+    if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
+    if (wire_count == 0) return ACX_OK;
+    acx_ctx* c = r->ctx;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    ACX_TRY(ensure_csc(r));
+    const uint64_t N = 1ull << r->log_n, n = nv->n;
+    DevBuf dense, res, tmp;
+    ACX_TRY(dense.alloc(wire_count * N * 32));
+    ACX_TRY(res.alloc(wire_count * n * 32));
+    ACX_TRY(tmp.alloc(wire_count * n * 32));
+    HIP_TRY(hipMemsetAsync(dense.p, 0, wire_count * N * 32, c->stream));
+    const DevMatrix& T = r->T[matrix];
+    if (T.nnz)
+        hipLaunchKernelGGL(k_scatter_columns, dim3(grid_for(c, T.nnz)), dim3(kBlock), 0, c->stream, (const u32*)T.ptr,
+                           (const u32*)T.idx, (const uint4*)T.val, wire_begin, wire_count, r->log_n, dense.as<uint4>());
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_matvec_q<F>), dim3(grid_for(c, wire_count * n)), dim3(kBlock), 0, c->stream,
+                                         (const uint4*)dense.as<uint4>(), N, (const uint4*)nv->Q, (u32)n, wire_count,
+                                         res.as<uint4>(), n));
+    HIP_TRY(hipGetLastError());
+    ACX_TRY(download_elements(c, res.as<uint4>(), wire_count * n, out, tmp.as<uint4>()));
+    if (out_len) {
+        static const uint8_t zero32[32] = {0};
+        for (uint64_t w = 0; w < wire_count; ++w) {
+            uint64_t len = n;
+            while (len > 0 && std::memcmp(out[w * n + len - 1].b, zero32, 32) == 0) --len;
+            out_len[w] = len;
+        }
+    }
+    return ACX_OK;
+}
+
+int acx_naive_h(acx_naive* nv, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok) {
+    if (!nv || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    acx_r1cs* r = nv->r;
+    acx_ctx* c = r->ctx;
+    const HostField& hf = c->hf;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t N = 1ull << r->log_n;
+    const uint32_t n = nv->n, np1 = n + 1;
+    DevBuf dots, lro, prod, quot;
+    ACX_TRY(dots.alloc(3 * N * 32));
+    ACX_TRY(lro.alloc((size_t)3 * np1 * 32));
+    ACX_TRY(prod.alloc((size_t)(2 * np1) * 32));
+    ACX_TRY(quot.alloc((size_t)(np1 + 1) * 32));
+    HIP_TRY(hipMemsetAsync(dots.p, 0, 3 * N * 32, c->stream));
+    HIP_TRY(hipMemsetAsync(lro.p, 0, (size_t)3 * np1 * 32, c->stream));
+    HIP_TRY(hipMemsetAsync(quot.p, 0, (size_t)(np1 + 1) * 32, c->stream));
+    uint64_t bad = 0;
+    ACX_TRY(verify_common(r, witness, &bad, nullptr, nullptr, dots.as<uint4>(), N));
+    H256 dl[3] = {hf.zero(), hf.zero(), hf.zero()};
+    if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], hf, dl[k]));
+    uint4* L = lro.as<uint4>();
+    uint4* R = L + 2 * (u64)np1;
+    uint4* O = R + 2 * (u64)np1;
+    // L0, R0, O0 = interpolants of the dot products on the roots (n coefficients each, stride n+1)
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_matvec_q<F>), dim3(grid_for(c, 3ull * n)), dim3(kBlock), 0, c->stream,
+                                         (const uint4*)dots.as<uint4>(), N, (const uint4*)nv->Q, n, (u64)3, L, (u64)np1));
+    // + delta_k * T   (src/QAP.hs:315-323)
+    const FeArg one = dev_arg(hf, hf.one());
+    for (int k = 0; k < 3; ++k)
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_poly_axpby<F>), dim3(grid_for(c, np1)), dim3(kBlock), 0, c->stream,
+                                             L + 2 * (u64)k * np1, (const uint4*)nv->tcoef, np1, one, dev_arg(hf, dl[k])));
+    // P = L*R - O  (2n+1 coefficients), then quotRem by T
+    DISPATCH_FIELD(c, {
+        hipLaunchKernelGGL((k_poly_mul<F>), dim3((2 * np1 - 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                           (const uint4*)L, np1, (const uint4*)R, np1, prod.as<uint4>());
+        hipLaunchKernelGGL((k_poly_axpby<F>), dim3(grid_for(c, np1)), dim3(kBlock), 0, c->stream, prod.as<uint4>(),
+                           (const uint4*)O, np1, one, dev_arg(hf, hf.neg(hf.one())));
+        hipLaunchKernelGGL((k_poly_divrem_monic<F>), dim3(1), dim3(1024), 0, c->stream, prod.as<uint4>(), 2 * np1 - 1,
+                           (const uint4*)nv->tcoef, n, quot.as<uint4>());
+    });
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, 4, c->stream));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_any_nonzero<F>), dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream,
+                                         (const uint4*)prod.as<uint4>(), n, c->d_err));
+    HIP_TRY(hipGetLastError());
+    uint32_t rem_nonzero = 0;
+    HIP_TRY(hipMemcpyAsync(&rem_nonzero, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    ACX_TRY(download_elements(c, quot.as<uint4>(), np1, out_h, lro.as<uint4>()));
+    *ok = rem_nonzero == 0;
+    if ((bad == 0) != (*ok != 0)) return fail(ACX_ERR_HIP, "internal: division remainder disagrees with the residual check");
+    uint64_t len = np1;
+    static const uint8_t zero32[32] = {0};
+    while (len > 0 && std::memcmp(out_h[len - 1].b, zero32, 32) == 0) --len;
+    *h_len = len;
     return ACX_OK;
 }
 

@@ -473,6 +473,142 @@ __global__ __launch_bounds__(kBlock) void k_axpy2(uint4* __restrict__ h, const u
 }
 
 // ---------------------------------------------------------------------------------------------
+// Naive-roots path: `createPolynomials` (src/QAP.hs:486-508) = Lagrange interpolation on ARBITRARY
+// distinct roots with target T(x) = prod (x - r_i).  The reference calls its own version "terrible
+// complexity" and uses it at test sizes only (roots 7,8,9 in test/Test/QAP.hs:73); these kernels
+// are plain O(n^2) and are not tuned.  n <= 4096.
+//
+// T coefficients, low to high, n + 1 of them (monic).  One workgroup; n sequential steps.
+template <class F>
+__global__ __launch_bounds__(1024) void k_poly_from_roots(const uint4* __restrict__ roots, u32 n,
+                                                         uint4* __restrict__ coef, uint4* __restrict__ tmp) {
+    // coef holds the running product of degree d (d+1 coefficients); multiply by (x - r_d)
+    for (u32 i = threadIdx.x; i <= n; i += blockDim.x) fe_store(coef + 2 * (u64)i, i == 0 ? fe_one_mont<F>() : fe_zero());
+    __syncthreads();
+    for (u32 d = 0; d < n; ++d) {
+        const Fe r = fe_load(roots + 2 * (u64)d);
+        for (u32 i = threadIdx.x; i <= d + 1; i += blockDim.x) {
+            // new[i] = old[i-1] - r * old[i]
+            const Fe lo = (i >= 1) ? fe_load(coef + 2 * (u64)(i - 1)) : fe_zero();
+            const Fe hi = (i <= d) ? fe_mul<F>(r, fe_load(coef + 2 * (u64)i)) : fe_zero();
+            fe_store(tmp + 2 * (u64)i, fe_sub<F>(lo, hi));
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i <= d + 1; i += blockDim.x) {
+            coef[2 * (u64)i] = tmp[2 * (u64)i];
+            coef[2 * (u64)i + 1] = tmp[2 * (u64)i + 1];
+        }
+        __syncthreads();
+    }
+}
+
+// a^(p-2): exponent given as 8 x u32 words (host-computed p - 2)
+struct Exp256 { u32 w[8]; };
+template <class F>
+__device__ __forceinline__ Fe fe_inv_exp(const Fe& a, const Exp256& e) {
+    Fe acc = fe_one_mont<F>(), base = a;
+    for (int i = 0; i < 256; ++i) {
+        if ((e.w[i >> 5] >> (i & 31)) & 1) acc = fe_mul<F>(acc, base);
+        base = fe_mul<F>(base, base);
+    }
+    return acc;
+}
+
+// winv[i] = 1 / T'(r_i) = 1 / prod_{j != i} (r_i - r_j)   (`phis`, src/QAP.hs:503-504)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_bary_inv(const uint4* __restrict__ roots, u32 n, uint4* __restrict__ winv,
+                                                    Exp256 pm2) {
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Fe ri = fe_load(roots + 2 * (u64)i);
+    Fe acc = fe_one_mont<F>();
+    for (u32 j = 0; j < n; ++j)
+        if (j != i) acc = fe_mul<F>(acc, fe_sub<F>(ri, fe_load(roots + 2 * (u64)j)));
+    fe_store(winv + 2 * (u64)i, fe_inv_exp<F>(acc, pm2));
+}
+
+// Q[i][k] = coefficient k of  winv[i] * T(x) / (x - r_i)   (synthetic division; `roots `quot` root x`
+// scaled by 1/phi, src/QAP.hs:496-500), k < n.  One thread per i.
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_build_q(const uint4* __restrict__ roots, const uint4* __restrict__ tcoef,
+                                                   const uint4* __restrict__ winv, u32 n, uint4* __restrict__ Q) {
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Fe ri = fe_load(roots + 2 * (u64)i), wi = fe_load(winv + 2 * (u64)i);
+    Fe q = fe_load(tcoef + 2 * (u64)n);                      // leading coefficient (1)
+    for (u32 k = n; k-- > 0;) {                               // q_k = T[k+1] + r_i * q_{k+1}
+        fe_store(Q + 2 * ((u64)i * n + k), fe_mul<F>(q, wi));
+        q = fe_add<F>(fe_load(tcoef + 2 * (u64)k), fe_mul<F>(ri, q));
+    }
+}
+
+// out[b][k] = sum_i vals[b * val_stride + i] * Q[i][k]      (Lagrange sum, src/QAP.hs:496-500)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_matvec_q(const uint4* __restrict__ vals, u64 val_stride,
+                                                    const uint4* __restrict__ Q, u32 n, u64 batch,
+                                                    uint4* __restrict__ out, u64 out_stride) {
+    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < batch * n; t += (u64)gridDim.x * kBlock) {
+        const u64 b = t / n;
+        const u32 k = (u32)(t - b * n);
+        Fe acc = fe_zero();
+        for (u32 i = 0; i < n; ++i) {
+            const Fe v = fe_load(vals + 2 * (b * val_stride + i));
+            if (fe_is_zero<F>(v)) continue;                    // columns are sparse
+            acc = fe_add<F>(acc, fe_mul<F>(v, fe_load(Q + 2 * ((u64)i * n + k))));
+        }
+        fe_store(out + 2 * (b * out_stride + k), acc);
+    }
+}
+
+// c[k] = sum_{i+j=k} a[i] * b[j], a: na coefficients, b: nb  (schoolbook; poly `*`, src/QAP.hs:325)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_poly_mul(const uint4* __restrict__ a, u32 na, const uint4* __restrict__ b,
+                                                    u32 nb, uint4* __restrict__ c) {
+    const u32 k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= na + nb - 1) return;
+    Fe acc = fe_zero();
+    const u32 i0 = k >= nb ? k - nb + 1 : 0, i1 = k < na ? k : na - 1;
+    for (u32 i = i0; i <= i1; ++i) acc = fe_add<F>(acc, fe_mul<F>(fe_load(a + 2 * (u64)i), fe_load(b + 2 * (u64)(k - i))));
+    fe_store(c + 2 * (u64)k, acc);
+}
+
+// y[i] = y[i] * sy + x[i] * sx   (sy, sx constants; used for L = L0 + delta*T and P = L*R - O)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_poly_axpby(uint4* __restrict__ y, const uint4* __restrict__ x, u32 n,
+                                                      FeArg sy_arg, FeArg sx_arg) {
+    const Fe sy = fe_from_arg(sy_arg), sx = fe_from_arg(sx_arg);
+    for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const Fe t = fe_add<F>(fe_mul<F>(fe_load(y + 2 * (u64)i), sy), fe_mul<F>(fe_load(x + 2 * (u64)i), sx));
+        fe_store(y + 2 * (u64)i, t);
+    }
+}
+
+// Long division of P (np coefficients, destroyed: becomes the remainder in its low n coefficients)
+// by the MONIC T of degree n (`quotRem`, src/QAP.hs:327).  quot gets np - n coefficients.
+// One workgroup; np - n sequential steps.
+template <class F>
+__global__ __launch_bounds__(1024) void k_poly_divrem_monic(uint4* __restrict__ P, u32 np, const uint4* __restrict__ T,
+                                                           u32 n, uint4* __restrict__ quot) {
+    if (np <= n) return;
+    for (u32 s = np - n; s-- > 0;) {               // quotient coefficient s = P[s + n]
+        const Fe q = fe_load(P + 2 * (u64)(s + n));
+        if (threadIdx.x == 0) fe_store(quot + 2 * (u64)s, q);
+        for (u32 j = threadIdx.x; j < n; j += blockDim.x) {
+            const Fe t = fe_sub<F>(fe_load(P + 2 * (u64)(s + j)), fe_mul<F>(q, fe_load(T + 2 * (u64)j)));
+            fe_store(P + 2 * (u64)(s + j), t);
+        }
+        __syncthreads();
+    }
+}
+
+// flag[0] |= 1 if any of the n elements is nonzero mod p
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_any_nonzero(const uint4* __restrict__ x, u32 n, u32* __restrict__ flag) {
+    for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        if (!fe_is_zero<F>(fe_load(x + 2 * (u64)i))) atomicOr(flag, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K6: densify columns [wire_begin, wire_begin+wire_count) of one matrix from its CSC form into
 // out[w][0..N) (zero filled beforehand) -- the per-wire `Map root value` of the GenQAP
 // (src/QAP.hs:94-99) after `addMissingZeroes` (src/QAP.hs:566-576), only for a batch of wires.

@@ -184,6 +184,49 @@ class R1CS:
         check(self.ctx.lib.acx_r1cs_verify_dev(self._h, d_witness, row_offset, d_result, d_residuals or None, d_dots or None))
 
 
+class Naive:
+    """acx_naive: createPolynomials on arbitrary distinct roots (Lagrange), n <= 4096."""
+
+    def __init__(self, r1cs: R1CS, roots: Sequence[int]):
+        self.r1cs = r1cs
+        self.lib = r1cs.ctx.lib
+        rr = ints_to_fr(list(roots))
+        h = C.c_void_p()
+        check(self.lib.acx_naive_create(r1cs._h, _ptr(rr), rr.shape[0], C.byref(h)))
+        self._h = h
+        self.n = r1cs.n
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.r1cs, "_h", None):
+            self.lib.acx_naive_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def target(self) -> np.ndarray:
+        out = np.zeros((self.n + 1, 4), dtype=np.uint64)
+        check(self.lib.acx_naive_target(self._h, _ptr(out)))
+        return out
+
+    def columns(self, matrix: int, wire_begin: int, wire_count: int) -> Tuple[np.ndarray, np.ndarray]:
+        out = np.zeros((wire_count, self.n, 4), dtype=np.uint64)
+        lens = np.zeros(wire_count, dtype=np.uint64)
+        check(self.lib.acx_naive_columns(self._h, matrix, wire_begin, wire_count, _ptr(out), _ptr(lens)))
+        return out, lens
+
+    def h(self, witness: np.ndarray, delta: Optional[Sequence[int]] = None) -> Tuple[Optional[np.ndarray], bool]:
+        w = _fr_array(witness, self.r1cs.m)
+        out = np.zeros((self.n + 1, 4), dtype=np.uint64)
+        dl = ints_to_fr(list(delta)) if delta is not None else None
+        hlen, ok = C.c_uint64(), C.c_int()
+        check(self.lib.acx_naive_h(self._h, _ptr(w), _ptr(dl), _ptr(out), C.byref(hlen), C.byref(ok)))
+        return (out[: hlen.value] if ok.value else None), bool(ok.value)
+
+
 class Batch:
     """acx_batch: many (R1CS, device witness) pairs verified by one launch."""
 

@@ -21,7 +21,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 from .circuit import ArithCircuit, Equal, Gate, Mul, Split, Wire
-from .engine import Circuit, Context, R1CS, fr_to_ints, ints_to_fr
+from .engine import Circuit, Context, Naive, R1CS, fr_to_ints, ints_to_fr
 
 
 @dataclass
@@ -106,6 +106,24 @@ class QAP:
         return self._polys(2, wire, flat)
 
 
+class NaiveQAP(QAP):
+    """`data QAP f` produced by `createPolynomials` / `arithCircuitToQAP` (src/QAP.hs:486-508,
+    542-549): interpolation on the actual root values, qapTarget = prod (x - r)."""
+
+    def __init__(self, gen: GenQAP, sorted_roots: Sequence[int]):
+        super().__init__(gen)
+        self.naive = Naive(gen.r1cs, sorted_roots)
+
+    @property
+    def qapTarget(self) -> List[int]:
+        return fr_to_ints(self.naive.target())
+
+    def _polys(self, matrix: int, wire: Wire = None, flat: int = None) -> List[int]:
+        k = flat if flat is not None else self.gen.flat_index(wire)
+        coeffs, lens = self.naive.columns(matrix, k, 1)
+        return fr_to_ints(coeffs[0, : int(lens[0])])
+
+
 def _roots_array(p: int, roots: Optional[Sequence[Sequence[int]]], rows_per_gate) -> Optional[np.ndarray]:
     if roots is None:
         return None
@@ -137,6 +155,18 @@ def arithCircuitToQAPFFT(ctx: Context, roots, circuit: ArithCircuit) -> QAP:
     return createPolynomialsFFT(arithCircuitToGenQAP(ctx, roots, circuit))
 
 
+def createPolynomials(gen: GenQAP, roots: Sequence[Sequence[int]]) -> NaiveQAP:
+    """src/QAP.hs:486-508.  The GenQAP here does not carry the root values (rows are stored in
+    ascending-root order), so they are passed again."""
+    p = gen.ctx.p
+    return NaiveQAP(gen, sorted(r % p for rs in roots for r in rs))
+
+
+def arithCircuitToQAP(ctx: Context, roots: Sequence[Sequence[int]], circuit: ArithCircuit) -> NaiveQAP:
+    """src/QAP.hs:542-549."""
+    return createPolynomials(arithCircuitToGenQAP(ctx, roots, circuit), roots[: len(circuit.gates)])
+
+
 def gateToQAP(ctx: Context, roots: Sequence[int], gate: Gate) -> QAP:
     return arithCircuitToQAPFFT(ctx, [list(roots)], ArithCircuit([gate]))
 
@@ -148,7 +178,11 @@ def verifyAssignment(qap: QAP, assignment: QapSet) -> bool:
 
 def verificationWitnessZk(delta1: int, delta2: int, delta3: int, qap: QAP, assignment: QapSet) -> Optional[List[int]]:
     p = qap.gen.ctx.p
-    h, ok = qap.gen.r1cs.qap_h(qap.gen.witness_vector(assignment), [delta1 % p, delta2 % p, delta3 % p])
+    d = [delta1 % p, delta2 % p, delta3 % p]
+    if isinstance(qap, NaiveQAP):
+        h, ok = qap.naive.h(qap.gen.witness_vector(assignment), d)
+    else:
+        h, ok = qap.gen.r1cs.qap_h(qap.gen.witness_vector(assignment), d)
     return fr_to_ints(h) if ok else None
 
 

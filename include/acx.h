@@ -182,6 +182,25 @@ int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* o
 int acx_qap_columns(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count,
                     acx_fr* out, uint64_t* out_len);
 
+/* ---------------------------------------------------------------- naive-roots path
+ * `createPolynomials` / `arithCircuitToQAP` (src/QAP.hs:486-508,542-549): Lagrange interpolation
+ * on ARBITRARY distinct roots, target T(x) = prod (x - r_i) -- what the reference's unit tests use
+ * (roots 7,8,9: test/Test/QAP.hs:73-74).  roots[i] belongs to row i of the system, which
+ * acx_circuit_to_r1cs stores in ascending-root order, so roots must be strictly ascending.
+ * O(n^2) like the reference's ("terrible complexity", src/QAP.hs:483-485); n <= 4096.
+ * verifyAssignment itself needs no roots: use acx_r1cs_verify. */
+typedef struct acx_naive acx_naive;
+int acx_naive_create(acx_r1cs* r, const acx_fr* roots, uint64_t n_roots, acx_naive** out);
+void acx_naive_destroy(acx_naive* nv);
+/* qapTarget: n + 1 coefficients, low to high (monic). */
+int acx_naive_target(acx_naive* nv, acx_fr* out);
+/* Per-wire polynomials of one matrix: out[w*n .. w*n+n), out_len[w] = stripped length. */
+int acx_naive_columns(acx_naive* nv, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out,
+                      uint64_t* out_len);
+/* verificationWitnessZk on the naive QAP: quotient of (L*R - O) by T; out_h holds n + 1 elements. */
+int acx_naive_h(acx_naive* nv, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len,
+                int* ok);
+
 /* ---------------------------------------------------------------- NTT (replaces galois-fft) */
 /* batch independent length-2^log_n transforms on host data, in place semantic (in may == out).
  * inverse = 0: out[k] = sum_i in[i] * (shift*omega^k)^i  (`FFT.fft`; shift NULL = 1)

@@ -402,3 +402,81 @@ def test_generic_random_csr_vs_oracle(request, acx, field, seed):
     h2, ok2 = r2.qap_h(w2, d)
     want_h, want_ok = orc.qap_h(65, 4, r2.log_n, mk(1), mk(2), mk(3), w2, delta=d)
     assert ok2 and want_ok and acx.fr_to_ints(h2) == R.to_poly(limbs_to_ints(want_h), p)
+
+
+# ------------------------------------------------------------------ naive-roots path (createPolynomials / arithCircuitToQAP)
+def _kat_program(acx):
+    """testArithCircuit, test/Test/QAP.hs:48-54."""
+    return acx.ArithCircuit([
+        acx.Mul(acx.Var(acx.InputWire(0)), acx.Var(acx.InputWire(1)), acx.IntermediateWire(0)),
+        acx.Mul(acx.Var(acx.InputWire(2)), acx.Var(acx.InputWire(3)), acx.IntermediateWire(1)),
+        acx.Mul(acx.Add(acx.ConstGate(10), acx.Var(acx.IntermediateWire(0))), acx.Var(acx.IntermediateWire(1)), acx.OutputWire(0))])
+
+
+def test_unit_arithCircuitToQapCorrect_and_NoFalsePositive(request, acx):
+    """test/Test/QAP.hs:68-90 verbatim shape: naive roots [[7],[8],[9]] through `arithCircuitToQAP`;
+    plus the derived coefficient KATs of SURVEY.md Appendix A.6."""
+    ctx = _ctx(request, "bn254")
+    p = ctx.p
+    roots = [[7], [8], [9]]
+    qap = acx.arithCircuitToQAP(ctx, roots, _kat_program(acx))
+    assignment = acx.generateAssignment(_kat_program(acx), {0: 2, 1: 3, 2: 4, 3: 5})
+    assert acx.verifyAssignment(qap, assignment)
+    invalid = acx.QapSet(1, {0: 2, 1: 3, 2: 4, 3: 5}, {0: 7, 1: 20}, {0: 320})
+    assert not acx.verifyAssignment(qap, invalid)
+    sgn = lambda xs: [x if x < p // 2 else x - p for x in xs]
+    assert sgn(qap.qapTarget) == [-504, 191, -24, 1]
+    assert sgn(qap.qapInputsLeft(flat=0)) == [280, -75, 5]
+    h = acx.verificationWitness(qap, assignment)
+    assert h is not None and len(h) == 2
+    assert acx.verificationWitness(qap, invalid) is None
+
+
+@pytest.mark.parametrize("field,seed", [("bn254", 0), ("bn254", 1), ("bls12_381", 2)])
+def test_prop_arithCircuitToQAP_slow_gpu(request, acx, field, seed):
+    """test/Test/Circuit/Arithmetic.hs:188-198 (roots 1..n, naive Lagrange) against the literal
+    oracle: target, every per-wire polynomial, h(x) and its zero-knowledge variant, coefficient for
+    coefficient; a corrupted assignment gives Nothing."""
+    ctx = _ctx(request, field)
+    fld = FIELDS[field]
+    p = fld.p
+    rnd = random.Random(9000 + seed)
+    nv = rnd.randrange(1, 5)
+    gates = H.arb_arith_circuit(rnd, p, nv, 6 + seed, dist=(50, 10, 3), split_bits=5)
+    program = H.to_acx_circuit(acx, gates)
+    roots = R.fresh_roots(gates, 1)
+    if seed == 1:                       # arbitrary, unsorted, large roots
+        flat = rnd.sample(range(1, 10 ** 6), sum(len(r) for r in roots)) 
+        it = iter(flat)
+        roots = [[next(it) for _ in rs] for rs in roots]
+    qap = acx.arithCircuitToQAP(ctx, roots, program)
+    want = R.arith_circuit_to_qap(roots, gates, p)
+    assert qap.qapTarget == want.target
+    dims = H.circuit_dims(gates)
+    for getter, qs in ((qap.qapInputsLeft, want.left), (qap.qapInputsRight, want.right), (qap.qapOutputs, want.out)):
+        assert getter(flat=0) == qs.constant
+        for kind, part in enumerate((qs.inputs, qs.intermediates, qs.outputs)):
+            for idx, poly in part.items():
+                assert getter(flat=H.flat_index(dims, R.Wire(kind, idx))) == poly
+    for t in range(3):
+        inp = H.arb_input_vector(rnd, p, nv)
+        ra = R.generate_assignment(gates, inp, p)
+        a = _acx_qapset(acx, ra)
+        assert acx.verifyAssignment(qap, a)
+        assert acx.verificationWitness(qap, a) == R.verification_witness(want, ra, p)
+        d = [rnd.randrange(p) for _ in range(3)]
+        assert acx.verificationWitnessZk(d[0], d[1], d[2], qap, a) == R.verification_witness_zk(d[0], d[1], d[2], want, ra, p)
+        k = sorted(ra.intermediates)[0]
+        ra.intermediates[k] = (ra.intermediates[k] + 1) % p
+        assert acx.verificationWitness(qap, _acx_qapset(acx, ra)) is None and R.verification_witness(want, ra, p) is None
+
+
+def test_naive_errors(request, acx):
+    ctx = _ctx(request, "bn254")
+    gen = acx.arithCircuitToGenQAP(ctx, [[7], [8], [9]], _kat_program(acx))
+    with pytest.raises(acx.AcxError) as e:
+        acx.Naive(gen.r1cs, [7, 8])
+    assert e.value.status == acx._lib.STATUS["ROOT_COUNT"]
+    with pytest.raises(acx.AcxError) as e:
+        acx.Naive(gen.r1cs, [7, 9, 8])
+    assert e.value.status == acx._lib.STATUS["DUPLICATE_ROOT"]
