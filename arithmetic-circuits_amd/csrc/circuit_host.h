@@ -284,6 +284,65 @@ public:
         return ACX_OK;
     }
 
+    // Level schedule for evaluating the circuit on the GPU.  Possible when the
+    // gate list is in single-assignment form: every intermediate/output wire is written by at most
+    // one gate and only read by later gates (what `validArithCircuit` guarantees for reads; the
+    // reference itself would let a later gate overwrite a wire -- such circuits keep the host path).
+    struct EvalPlan {
+        std::vector<uint32_t> level_ofs;   // [n_levels + 1] into items
+        std::vector<uint32_t> items;       // gate ids, grouped by level
+        std::vector<uint8_t> written;      // [m] wire is assigned by some gate (or is the constant)
+    };
+    bool build_plan(EvalPlan& plan) const {
+        const uint64_t M = m();
+        std::vector<int64_t> writer(M, -1);
+        for (uint64_t g = 0; g < n_gates; ++g) {
+            const acx_wire* gw = &wires[wire_ofs[g]];
+            const uint64_t nw = wire_ofs[g + 1] - wire_ofs[g];
+            auto claim = [&](const acx_wire& w) {
+                const uint64_t k = flat(w);
+                if (w.kind == ACX_WIRE_INPUT || writer[k] >= 0) return false;   // inputs are never gate outputs here
+                writer[k] = (int64_t)g;
+                return true;
+            };
+            if (kind[g] == ACX_GATE_MUL) { if (!claim(gw[0])) return false; }
+            else if (kind[g] == ACX_GATE_EQUAL) { if (gw[1].kind == gw[2].kind && gw[1].index == gw[2].index) return false;
+                                                   if (!claim(gw[1]) || !claim(gw[2])) return false; }
+            else for (uint64_t j = 1; j < nw; ++j) if (!claim(gw[j])) return false;
+        }
+        std::vector<uint32_t> level(n_gates, 0);
+        uint32_t n_levels = 0;
+        for (uint64_t g = 0; g < n_gates; ++g) {
+            const acx_wire* gw = &wires[wire_ofs[g]];
+            uint32_t lv = 0;
+            bool ok = true;
+            auto dep = [&](const acx_wire& w) {
+                if (w.kind == ACX_WIRE_INPUT) return;
+                const int64_t wr = writer[flat(w)];
+                if (wr < 0) return;                        // never written: reads as absent
+                if ((uint64_t)wr >= g) { ok = false; return; }   // written later: order-dependent
+                lv = std::max(lv, level[wr] + 1);
+            };
+            if (kind[g] == ACX_GATE_MUL) {
+                for (uint64_t t = tok_ofs[2 * g]; t < tok_ofs[2 * g + 2]; ++t)
+                    if (tok_op[t] == ACX_AFF_VAR) dep(aff_wires[tok_arg[t]]);
+            } else dep(gw[0]);
+            if (!ok) return false;
+            level[g] = lv;
+            n_levels = std::max(n_levels, lv + 1);
+        }
+        plan.level_ofs.assign(n_levels + 1, 0);
+        for (uint64_t g = 0; g < n_gates; ++g) ++plan.level_ofs[level[g] + 1];
+        for (uint32_t l = 0; l < n_levels; ++l) plan.level_ofs[l + 1] += plan.level_ofs[l];
+        plan.items.resize(n_gates);
+        std::vector<uint32_t> cur(plan.level_ofs.begin(), plan.level_ofs.end() - 1);
+        for (uint64_t g = 0; g < n_gates; ++g) plan.items[cur[level[g]]++] = (uint32_t)g;
+        plan.written.assign(M, 0);
+        plan.written[0] = 1;
+        for (uint64_t k = 0; k < M; ++k) if (writer[k] >= 0) plan.written[k] = 1;
+        return true;
+    }
+
     bool valid() const {
         std::vector<uint8_t> defined(n_mid, 0);
         bool res = true;

@@ -81,6 +81,14 @@ struct acx_r1cs {
     u32* perm = nullptr;
     u32* long_rows = nullptr;
     uint32_t n_slices = 0, n_long = 0;
+    // device evaluation plan (present when the system was built from a single-assignment circuit)
+    bool has_plan = false;
+    std::vector<uint32_t> plan_level_ofs;
+    std::vector<uint8_t> plan_written, plan_kind;   // host copies for argument checks
+    std::vector<uint32_t> plan_eq_split_inputs;     // flat input wire of every Equal / Split gate
+    uint64_t plan_n_in = 0;
+    u32 *ev_items = nullptr, *ev_row = nullptr, *ev_wire_ofs = nullptr, *ev_wires = nullptr;
+    uint8_t* ev_kind = nullptr;
     bool has_csc = false;
     uint4* d_w = nullptr;  // witness staging, m elements
 };
@@ -555,6 +563,12 @@ void free_r1cs_device(acx_r1cs* r) {
     }
     if (r->perm) (void)hipFree(r->perm);
     if (r->long_rows) (void)hipFree(r->long_rows);
+    if (r->ev_items) (void)hipFree(r->ev_items);
+    if (r->ev_row) (void)hipFree(r->ev_row);
+    if (r->ev_wire_ofs) (void)hipFree(r->ev_wire_ofs);
+    if (r->ev_wires) (void)hipFree(r->ev_wires);
+    if (r->ev_kind) (void)hipFree(r->ev_kind);
+    r->ev_items = r->ev_row = r->ev_wire_ofs = r->ev_wires = nullptr; r->ev_kind = nullptr;
     if (r->d_w) (void)hipFree(r->d_w);
     r->perm = nullptr; r->long_rows = nullptr; r->d_w = nullptr;
 }
@@ -850,7 +864,39 @@ int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots,
         views[k] = acx_csr{src->rowptr.data(), src->col.data(), reinterpret_cast<const acx_fr*>(src->val.data())};
     }
     const acx_csr* mats[3] = {&views[0], &views[1], &views[2]};
-    return r1cs_from_host(ctx, hc.n_rows(), hc.m(), mats, out);
+    ACX_TRY(r1cs_from_host(ctx, hc.n_rows(), hc.m(), mats, out));
+    // device evaluation plan (generateAssignment on the GPU), when the circuit allows it
+    HostCircuit::EvalPlan plan;
+    if (hc.n_gates > 0 && hc.n_gates < 0xffffffffull && hc.build_plan(plan)) {
+        acx_r1cs* r = *out;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        const uint64_t ng = hc.n_gates;
+        std::vector<uint32_t> inv(hc.n_rows());
+        if (order.empty()) for (uint64_t i = 0; i < inv.size(); ++i) inv[i] = (uint32_t)i;
+        else for (uint64_t i = 0; i < inv.size(); ++i) inv[order[i]] = (uint32_t)i;
+        std::vector<uint32_t> row(ng), wofs(ng + 1), wflat(hc.wires.size());
+        uint64_t first_row = 0;
+        for (uint64_t g = 0; g < ng; ++g) {
+            row[g] = inv[first_row];
+            first_row += hc.rows_of_gate(g);
+            wofs[g] = (uint32_t)hc.wire_ofs[g];
+            if (hc.kind[g] != ACX_GATE_MUL) r->plan_eq_split_inputs.push_back((uint32_t)hc.flat(hc.wires[hc.wire_ofs[g]]));
+        }
+        wofs[ng] = (uint32_t)hc.wire_ofs[ng];
+        for (size_t i = 0; i < hc.wires.size(); ++i) wflat[i] = (uint32_t)hc.flat(hc.wires[i]);
+        auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
+            return hipMalloc(dst, bytes ? bytes : 4) == hipSuccess && (bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
+        };
+        if (up((void**)&r->ev_items, plan.items.data(), plan.items.size() * 4) && up((void**)&r->ev_row, row.data(), row.size() * 4) &&
+            up((void**)&r->ev_wire_ofs, wofs.data(), wofs.size() * 4) && up((void**)&r->ev_wires, wflat.data(), wflat.size() * 4) &&
+            up((void**)&r->ev_kind, hc.kind.data(), hc.kind.size())) {
+            r->has_plan = true;
+            r->plan_level_ofs = plan.level_ofs;
+            r->plan_written = plan.written;
+            r->plan_n_in = hc.n_in;
+        }
+    }
+    return ACX_OK;
 }
 
 // ---------------------------------------------------------------------------------- R1CS
@@ -920,6 +966,71 @@ int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad
     *ok = bad == 0;
     if (n_bad) *n_bad = bad;
     if (first_bad) *first_bad = first;
+    return ACX_OK;
+}
+
+int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs, acx_fr* witness,
+                  uint8_t* assigned) {
+    if (!r || (n_inputs && !inputs)) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (!r->has_plan)
+        return fail(ACX_ERR_UNSUPPORTED, "no device evaluation plan (system not built from a single-assignment circuit)");
+    acx_ctx* c = r->ctx;
+    const HostField& hf = c->hf;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    // which wires hold a value afterwards (what the QapSet would contain)
+    std::vector<uint8_t> as(r->plan_written);
+    const uint64_t n_use = std::min<uint64_t>(n_inputs, r->plan_n_in);
+    for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) as[1 + i] = 1;
+    for (uint32_t k : r->plan_eq_split_inputs)
+        if (!as[k]) return fail(ACX_ERR_UNDEFINED_WIRE, "evalGate: the impossible happened (Equal/Split input unassigned)");
+    // initial witness: constant 1, the given inputs, everything else 0
+    std::vector<acx_fr> w0(r->m);
+    std::memset(w0.data(), 0, w0.size() * 32);
+    w0[0].b[0] = 1;
+    for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) w0[1 + i] = inputs[i];
+    ACX_TRY(upload_elements(c, w0.data(), r->m, r->d_w));
+    Exp256 pm2;
+    {
+        H256 ex = hf.modulus();
+        ex.l[0] -= 2;
+        for (int i = 0; i < 8; ++i) pm2.w[i] = (u32)(ex.l[i / 2] >> (32 * (i % 2)));
+    }
+    const CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val};
+    const size_t n_levels = r->plan_level_ofs.size() - 1;
+    for (size_t l = 0; l < n_levels; ++l) {
+        const uint32_t lo = r->plan_level_ofs[l], cnt = r->plan_level_ofs[l + 1] - lo;
+        if (cnt == 0) continue;
+        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires};
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level<F>), dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                                             G, A, B, r->d_w, pm2));
+    }
+    HIP_TRY(hipGetLastError());
+    if (witness) {
+        DevBuf tmp;
+        ACX_TRY(tmp.alloc(r->m * 32));
+        ACX_TRY(download_elements(c, r->d_w, r->m, witness, tmp.as<uint4>()));
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (assigned) std::memcpy(assigned, as.data(), as.size());
+    return ACX_OK;
+}
+
+int acx_r1cs_verify_resident(acx_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
+    if (!r || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    acx_ctx* c = r->ctx;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const unsigned long long init[2] = {0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(c->d_result, init, 16, hipMemcpyHostToDevice, c->stream));
+    ACX_TRY(launch_residual(r, r->d_w, 0, c->d_result, nullptr, nullptr, 0));
+    unsigned long long res[2];
+    HIP_TRY(hipMemcpyAsync(res, c->d_result, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *ok = res[0] == 0;
+    if (n_bad) *n_bad = res[0];
+    if (first_bad) *first_bad = res[1];
     return ACX_OK;
 }
 

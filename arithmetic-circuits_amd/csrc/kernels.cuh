@@ -609,6 +609,48 @@ __global__ __launch_bounds__(kBlock) void k_any_nonzero(const uint4* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Witness generation on the device: `evalArithCircuit` = foldl' evalGate (src/Circuit/Arithmetic.hs:
+// 106-145,221-235) restructured by dependency LEVEL: every gate of a level only reads wires written
+// by earlier levels, so a level is one data-parallel launch.  Mul: out = <A_row,w> * <B_row,w>, the
+// gate's own constraint row (src/QAP.hs:371-395); Equal: out = (inp /= 0), magic = inp^-1 (Fermat);
+// Split: bit j of the canonical integer.
+struct EvalGates {
+    const u32* items;        // gate ids of this level
+    u32 count;
+    const uint8_t* kind;     // per gate
+    const u32* row;          // per gate: constraint row of a Mul gate in the stored row order
+    const u32* wire_ofs;     // per gate: offset into wires (n_gates + 1)
+    const u32* wires;        // flat wire indices: Mul {out}, Equal {i, m, out}, Split {inp, outs...}
+};
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, CsrDev B, uint4* __restrict__ w,
+                                                      Exp256 pm2) {
+    const u32 t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= G.count) return;
+    const u32 g = G.items[t];
+    const u32* gw = G.wires + G.wire_ofs[g];
+    const u32 kd = G.kind[g];
+    if (kd == 0) {                                            // Mul
+        const u32 row = G.row[g];
+        const Fe a = csr_row_dot<F, false>(A, w, row), b = csr_row_dot<F, false>(B, w, row);
+        fe_store(w + 2 * (u64)gw[0], fe_mul<F>(a, b));
+    } else if (kd == 1) {                                     // Equal
+        const Fe inp = fe_load(w + 2 * (u64)gw[0]);
+        const bool z = fe_is_zero<F>(inp);
+        fe_store(w + 2 * (u64)gw[1], z ? fe_zero() : fe_inv_exp<F>(inp, pm2));
+        fe_store(w + 2 * (u64)gw[2], z ? fe_zero() : fe_one_mont<F>());
+    } else {                                                  // Split
+        const Fe c = fe_from_mont<F>(fe_load(w + 2 * (u64)gw[0]));
+        const u32 n_out = G.wire_ofs[g + 1] - G.wire_ofs[g] - 1;
+        for (u32 j = 0; j < n_out; ++j) {
+            const bool bit = j < 256 && ((c.l[j / kLimbBits] >> (j % kLimbBits)) & 1u);
+            fe_store(w + 2 * (u64)gw[1 + j], bit ? fe_one_mont<F>() : fe_zero());
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K6: densify columns [wire_begin, wire_begin+wire_count) of one matrix from its CSC form into
 // out[w][0..N) (zero filled beforehand) -- the per-wire `Map root value` of the GenQAP
 // (src/QAP.hs:94-99) after `addMissingZeroes` (src/QAP.hs:566-576), only for a batch of wires.

@@ -158,6 +158,21 @@ class R1CS:
         check(self.ctx.lib.acx_r1cs_verify(self._h, _ptr(w), C.byref(ok), C.byref(nbad), C.byref(first)))
         return bool(ok.value), nbad.value, first.value
 
+    def eval_witness(self, inputs: np.ndarray, present: Optional[np.ndarray] = None,
+                     download: bool = True) -> Tuple[Optional[np.ndarray], np.ndarray]:
+        """generateAssignment on the GPU (level-parallel); the witness stays device resident."""
+        inp = _fr_array(inputs) if len(inputs) else np.zeros((0, 4), dtype=np.uint64)
+        pres = np.ascontiguousarray(present, dtype=np.uint8) if present is not None else None
+        w = np.zeros((self.m, 4), dtype=np.uint64) if download else None
+        assigned = np.zeros(self.m, dtype=np.uint8)
+        check(self.ctx.lib.acx_r1cs_eval(self._h, _ptr(inp), _ptr(pres), inp.shape[0], _ptr(w), _ptr(assigned)))
+        return w, assigned
+
+    def verify_resident(self) -> Tuple[bool, int, int]:
+        ok, nbad, first = C.c_int(), C.c_uint64(), C.c_uint64()
+        check(self.ctx.lib.acx_r1cs_verify_resident(self._h, C.byref(ok), C.byref(nbad), C.byref(first)))
+        return bool(ok.value), nbad.value, first.value
+
     def residuals(self, witness: np.ndarray) -> np.ndarray:
         w = _fr_array(witness, self.m)
         out = np.zeros((self.n, 4), dtype=np.uint64)

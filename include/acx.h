@@ -165,6 +165,16 @@ int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* c
  * either may be NULL.  witness[m] canonical (absent wires = 0, `combineWithDefaults`
  * src/QAP.hs:163-181,314). */
 int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad);
+/* `generateAssignment` on the GPU: the gates are evaluated level by level (a
+ * level = gates whose inputs are all produced by earlier levels), one launch per level; Mul gates
+ * reuse their own constraint rows.  Available for systems built by acx_circuit_to_r1cs from a
+ * circuit in single-assignment form (else ACX_ERR_UNSUPPORTED: use acx_circuit_eval).  Same
+ * arguments and results as acx_circuit_eval; witness/assigned may be NULL.  The witness also stays
+ * resident on the device for acx_r1cs_verify_resident. */
+int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs,
+                  acx_fr* witness, uint8_t* assigned);
+/* verifyAssignment of the witness left on the device by acx_r1cs_eval / acx_r1cs_verify. */
+int acx_r1cs_verify_resident(acx_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* first_bad);
 /* Residual vector r_i (canonical), out[n]. */
 int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out);
 

@@ -480,3 +480,65 @@ def test_naive_errors(request, acx):
     with pytest.raises(acx.AcxError) as e:
         acx.Naive(gen.r1cs, [7, 9, 8])
     assert e.value.status == acx._lib.STATUS["DUPLICATE_ROOT"]
+
+
+# ------------------------------------------------------------------ generateAssignment on the GPU (level-parallel)
+@pytest.mark.parametrize("field,seed", [("bn254", 0), ("bn254", 1), ("bn254", 2), ("bls12_381", 3)])
+def test_gpu_witness_generation_equals_host(request, acx, field, seed):
+    """acx_r1cs_eval (one launch per dependency level) == acx_circuit_eval (the reference's
+    sequential fold, src/Circuit/Arithmetic.hs:221-235) on the reference's generator shapes
+    (Mul/Equal/Split 256 bits, zero inputs for the Equal gate's zero branch), then verifies."""
+    ctx = _ctx(request, field)
+    p = ctx.p
+    rnd = random.Random(9500 + seed)
+    nv = rnd.randrange(2, 6)
+    gates = H.arb_arith_circuit(rnd, p, nv, 15 + 12 * seed, dist=(50, 15, 4), split_bits=256)
+    program = H.to_acx_circuit(acx, gates)
+    circ = program.marshal(field)
+    r = circ.to_r1cs(ctx, acx.ints_to_fr([x for rs in acx.freshRoots(program, 1) for x in rs]))
+    for t in range(4):
+        inp = H.arb_input_vector(rnd, p, nv)
+        if t == 1:
+            inp = {k: 0 for k in inp}              # every Equal gate takes its zero branch
+        arr = acx.ints_to_fr([inp[i] for i in range(nv)])
+        want_w, want_as = circ.eval(arr)
+        got_w, got_as = r.eval_witness(arr)
+        assert np.array_equal(got_w, want_w) and np.array_equal(got_as, want_as)
+        assert r.verify_resident() == (True, 0, 2**64 - 1)
+        assert r.verify(want_w)[0]
+
+
+def test_gpu_witness_generation_mulgraph_and_errors(request, acx):
+    ctx = _ctx(request, "bn254")
+    synth = __import__("importlib").import_module("arithmetic-circuits_amd.synth")
+    s = synth.mulgraph(1 << 14, n_in=64, window=512, seed=77)
+    r = s.circuit.to_r1cs(ctx)
+    w, _ = r.eval_witness(s.inputs)
+    assert np.array_equal(w, s.witness())
+    assert r.verify_resident()[0]
+    # partially present inputs: absent keys read as 0 (fromMaybe 0, src/Circuit/Affine.hs:84)
+    pres = np.ones(64, dtype=np.uint8)
+    pres[3] = 0
+    w2, as2 = r.eval_witness(s.inputs, pres)
+    w2h, as2h = s.circuit.eval(s.inputs, pres)
+    assert np.array_equal(w2, w2h) and np.array_equal(as2, as2h)
+    # Equal gate on an absent input: the reference panics (src/Circuit/Arithmetic.hs:128)
+    eq = acx.ArithCircuit([acx.Equal(acx.InputWire(0), acx.IntermediateWire(0), acx.OutputWire(0))]).marshal()
+    re = eq.to_r1cs(ctx)
+    with pytest.raises(acx.AcxError) as e:
+        re.eval_witness(np.zeros((0, 4), dtype=np.uint64))
+    assert e.value.status == acx._lib.STATUS["UNDEFINED_WIRE"]
+    # a system loaded from raw CSR has no circuit to evaluate
+    raw = acx.R1CS.load(ctx, 1, 2, *[(np.array([0, 1], dtype=np.uint32), np.array([1], dtype=np.uint32), acx.ints_to_fr([1]))] * 3)
+    with pytest.raises(acx.AcxError) as e:
+        raw.eval_witness(np.zeros((0, 4), dtype=np.uint64))
+    assert e.value.status == acx._lib.STATUS["UNSUPPORTED"]
+    # a circuit that overwrites a wire keeps the host path
+    ow = acx.ArithCircuit([acx.Mul(acx.Var(acx.InputWire(0)), acx.Var(acx.InputWire(0)), acx.IntermediateWire(0)),
+                           acx.Mul(acx.Var(acx.IntermediateWire(0)), acx.ConstGate(2), acx.IntermediateWire(0))]).marshal()
+    ro = ow.to_r1cs(ctx)
+    with pytest.raises(acx.AcxError) as e:
+        ro.eval_witness(acx.ints_to_fr([3]))
+    assert e.value.status == acx._lib.STATUS["UNSUPPORTED"]
+    wh, _ = ow.eval(acx.ints_to_fr([3]))
+    assert acx.fr_to_ints(wh) == [1, 3, 18]
