@@ -11,3 +11,4 @@ from .qap import (GenQAP, NaiveQAP, QAP, QapSet, arithCircuitToGenQAP, arithCirc
                   createPolynomials, createPolynomialsFFT,
                   gateToQAP, generateAssignment, generateAssignmentGate, initialQapSet, lookupAtWire,
                   qapSetToMap, verificationWitness, verificationWitnessZk, verifyAssignment)
+from . import expr, json_io, parallel, synth  # noqa: E402  (host-side mirrors and utilities)
