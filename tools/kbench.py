@@ -79,6 +79,22 @@ def bench_ntt(ctx, stream, log_n, reps, batch=1):
           f"alg(128N) {128 * n * batch / us * 1e-3:.1f} GB/s")
 
 
+def bench_h(ctx, log_n):
+    """verificationWitness end to end (host witness in, host h out): residual dots + 7 NTT-sized passes."""
+    n = 1 << log_n
+    s = synth.mulgraph(n)
+    r = s.circuit.to_r1cs(ctx)
+    w = s.witness()
+    r.qap_h(w)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        h, ok = r.qap_h(w)
+    dt = (time.perf_counter() - t0) / reps
+    assert ok
+    print(f"qap_h n=2^{log_n}: {dt * 1e3:9.2f} ms per call (host in/out, includes H2D of w and D2H of h)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -93,6 +109,10 @@ def main():
             bench_r1cs(ctx, stream, ln, a.reps, a.copies if ln <= 18 else 1)
         if a.what in ("ntt", "all"):
             bench_ntt(ctx, stream, ln, a.reps)
+        if a.what == "nttbatch":
+            bench_ntt(ctx, stream, ln, a.reps, batch=64 if ln <= 20 else 8)
+        if a.what == "h":
+            bench_h(ctx, ln)
 
 
 if __name__ == "__main__":
