@@ -572,3 +572,26 @@ def test_prop_compiledQAPValid_gpu(request, acx, seed):
             assert acx.verificationWitness(qap_naive, a) is not None
         w, _ = qap_fft.gen.r1cs.eval_witness(acx.ints_to_fr([inputs[i] for i in range(nv)]))
         assert np.array_equal(w, qap_fft.gen.witness_vector(a))
+
+
+@pytest.mark.parametrize("field,log_n", [("bn254", 25), ("bls12_381", 26)])
+def test_ntt_four_pass_sizes_sparse_input(request, acx, field, log_n):
+    """N > 2^24 takes the 4-pass plan (digits of <= 8 bits).  The CPU oracle is too slow there, so the
+    input is a handful of impulses: X[k] = sum_j v_j w^(i_j k) is checked with big-int arithmetic at
+    sampled k, plus the inverse round trip on the full vector (size-independent properties)."""
+    ctx = _ctx(request, field)
+    p = ctx.p
+    N = 1 << log_n
+    rnd = random.Random(log_n)
+    pos = sorted(rnd.sample(range(N), 5)) + [0, N - 1]
+    vals = [rnd.randrange(1, p) for _ in pos]
+    x = np.zeros((N, 4), dtype=np.uint64)
+    x[pos] = acx.ints_to_fr(vals)
+    X = ctx.ntt(x, log_n)
+    w = ctx.root_of_unity(log_n)
+    ks = [0, 1, 2, N // 2, N - 1] + [rnd.randrange(N) for _ in range(40)]
+    got = acx.fr_to_ints(X[ks])
+    for k, g in zip(ks, got):
+        assert g == sum(v * pow(w, i * k, p) for i, v in zip(pos, vals)) % p, k
+    back = ctx.ntt(X, log_n, inverse=True)
+    assert np.array_equal(back, x)
