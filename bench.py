@@ -205,6 +205,13 @@ def main():
                          "kernel": "acx::k_r1cs_sell", "kernel_us": kernel_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["acx::k_r1cs_sell"]
+            if tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
+                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and not a.no_ntt:
             out["ntt"] = bench_ntt(ctx, stream, a.field)
         if world == 1 and not a.no_cpu and a.field == "bn254":
