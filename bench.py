@@ -79,8 +79,13 @@ def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=5):
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     ops = 1.5 * n * log_n + n
-    return {"workload": f"inverse NTT N=2^{log_n} ({field} Fr)", "us": us, "field_ops_per_s": ops / us * 1e6,
-            "algorithmic_GBps": 128 * n / us * 1e-3}
+    passes = 1 if log_n <= 8 else (log_n + 7) // 8
+    alg = 64 * passes * n          # one read + one write of every element per pass
+    return {"workload": f"inverse NTT N=2^{log_n} ({field} Fr), acx::k_ntt_tile x {passes} passes", "us": us,
+            "field_ops_per_s": ops / us * 1e6,
+            "roofline": {"bound": "hbm", "achieved": alg / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / us * 1e-3 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
+                         "note": "VALU-bound in practice: ~12.5 Montgomery products per element (profiles/r01_ntt_ablation.txt)"}}
 
 
 def main():
