@@ -47,7 +47,7 @@ def bench_r1cs(ctx, stream, log_n, reps, copies):
     n = 1 << log_n
     systems = []
     for c in range(copies):
-        s = synth.mulgraph(n, seed=0xAC355 + c)
+        s = synth.mulgraph(n, seed=0xAC355 + c, n_in=N_IN, window=WINDOW)
         mats = s.rows()
         r = s.circuit.to_r1cs(ctx)
         w = to_dev(ctx, s.witness())
@@ -95,13 +95,20 @@ def bench_h(ctx, log_n):
     print(f"qap_h n=2^{log_n}: {dt * 1e3:9.2f} ms per call (host in/out, includes H2D of w and D2H of h)")
 
 
+N_IN, WINDOW = 1024, 4096
+
+
 def main():
+    global N_IN, WINDOW
     ap = argparse.ArgumentParser()
+    ap.add_argument("--n-in", type=int, default=1024)
+    ap.add_argument("--window", type=int, default=4096)
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--logn", type=int, nargs="*", default=[16, 20])
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--copies", type=int, default=4)
     a = ap.parse_args()
+    N_IN, WINDOW = a.n_in, a.window
     ctx = acx.Context("bn254", 0)
     stream = torch.cuda.ExternalStream(ctx.stream)
     for ln in a.logn:

@@ -19,6 +19,8 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ table, co
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     v4 acc = {0, 0, 0, 0};
     uint32_t c = idx[tid & 0xfffff];
+    // every workgroup gathers from its OWN window (as the rows of different CUs do), not from one hot region
+    table += 2 * (uint64_t)((blockIdx.x % 64) * (mask + 1));
 #pragma unroll 8
     for (int it = 0; it < ITERS; ++it) {
         c = (c * 1664525u + 1013904223u) & mask;               // independent of the loaded data: throughput, not latency
@@ -65,7 +67,7 @@ int main() {
     CHECK(hipMemset(table, 1, (size_t)N * 32));
     std::vector<uint32_t> h(1 << 20); for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)(i * 2654435761u);
     CHECK(hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    for (uint32_t mask : {(1u << 12) - 1, (1u << 16) - 1, (1u << 20) - 1}) {
+    for (uint32_t mask : {(1u << 12) - 1, (1u << 13) - 1, (1u << 16) - 1}) {
         run<0>("A own element, lo+hi", table, idx, mask, out);
         run<1>("B paired lanes share an element", table, idx, mask, out);
         run<2>("C coalesced", table, idx, mask, out);
