@@ -228,6 +228,9 @@ __device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, cons
         }
     }
     const unsigned long long mask = __ballot(bad);
+#if defined(ACX_RING_ABL) && ACX_RING_ABL != 0
+    if (mask != 12345) return;                               // ablation builds compute garbage: no result atomics
+#endif
     if (mask == 0) return;                                   // wave-uniform
     unsigned long long my_first = bad ? (u64)row + out.row_offset : ~0ull;
     for (int off = 32; off > 0; off >>= 1) {
@@ -275,6 +278,266 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
         c = S.unit_c ? sell_dot<F, true>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
     }
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
+}
+
+#ifndef ACX_RING_ABL
+#define ACX_RING_ABL 0
+#endif
+// ---- K2r: producer/consumer form of K2 for large launches -------------------------------------
+// K2 above lets every wave fetch its own constraint stream, so the number of stream bytes in flight
+// per CU falls whenever its waves sit in a witness gather or in a multiply (PMC: ~56 L1 misses
+// outstanding per CU, 5.1 TB/s through the L1s).  Here one LOADER wave per workgroup streams the
+// A/B(/C) slots of the workgroup's slices into per-consumer LDS rings with global->LDS DMA
+// (global_load_lds_dwordx4: no VGPRs, ~30 KB in flight per CU at all times, independent of what the
+// other waves do) and kRingCons CONSUMER waves take their column words and value limbs from LDS, so
+// the only vector-memory requests a consumer makes are its witness gathers.
+//   ring slot  = 2 KiB value limbs 0-7 (two 1 KiB planes) + 512 B {limb 8, column}    (one SELL slot)
+//   filled[c]  = slots published to consumer c (written by the loader after the DMA landed: vmcnt)
+//   consumed[c]= slots consumer c has read out of LDS (the loader reuses a buffer after that)
+// Fills are issued round-robin over the consumers (slot j of every consumer's current slice, then
+// slot j+1, ...).  One workgroup = one CU (129 KiB of LDS); grid = parts x systems.
+constexpr u32 kRingWaves = 16;
+constexpr u32 kRingCons = kRingWaves - 1;
+constexpr u32 kRingDepth = 3;
+constexpr u32 kRingSlotBytes = 2560;
+constexpr u32 kRingMaxChunk = 1024;     // slices per workgroup (one 16-byte metadata record each)
+constexpr u32 kRingInFlight = 20;       // fills the loader keeps in flight: 60 DMA instructions (vmcnt counts to 63), 50 KB
+
+struct RingLds {
+    v4u32 slot[kRingCons][kRingDepth][kRingSlotBytes / 16];
+    v4u32 meta[kRingMaxChunk];          // {first A slot, first B slot, first C slot, nA | nB << 8 | nC << 16}
+    u32 filled[16];
+    u32 consumed[16];
+};
+// Every access goes through an LDS-address-space pointer: through a generic pointer hipcc emits
+// flat loads/stores, and a volatile flat store is followed by s_waitcnt vmcnt(0) -- which would
+// wait for every DMA (loader) or gather (consumer) in flight each time a flag is written.
+typedef __attribute__((address_space(3))) RingLds* RingPtr;
+typedef __attribute__((address_space(3))) const v2u32 lds_v2u32;
+
+__device__ __forceinline__ u32 lds_addr(const __attribute__((address_space(3))) void* p) { return (u32)(uintptr_t)p; }
+__device__ __forceinline__ u32 lds_peek(const __attribute__((address_space(3))) u32* p) {
+    return *(const volatile __attribute__((address_space(3))) u32*)p;
+}
+__device__ __forceinline__ void lds_poke(__attribute__((address_space(3))) u32* p, u32 v) {
+    *(volatile __attribute__((address_space(3))) u32*)p = v;
+}
+
+// One ring fill = one SELL slot: 2 x 1 KiB of value limbs (every lane 16 bytes, base + 16 * lane) and
+// 512 B of {limb 8, column} (lanes 0-31), landing at lds_byte, +1024 and +2048.  Hand-issued DMA:
+// hipcc does not see it, so it neither reserves VGPRs nor waits for it before later LDS reads;
+// completion is tracked with the explicit s_waitcnt vmcnt in ring_loader.
+__device__ __forceinline__ void ring_fill(u64 val_base, u64 tail_base, u32 lane16, u32 lds_byte) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"        // the offset applies to the LDS address too
+        "s_add_u32 m0, %4, 0x800\n\t"
+        "s_mov_b32 exec_hi, 0\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 exec_hi, -1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(lane16), "s"(val_base), "s"(tail_base), "s"(lds_byte) : "memory", "scc");
+}
+// The loader works in PASSES: pass j of a round issues slot j of every consumer's current slice
+// (<= 15 fills).  All per-consumer bookkeeping is lane-parallel (lane c = consumer c); only the DMA
+// issue itself loops over the consumers.  kRingInFlight fills stay in flight: after issuing fill f
+// the loader waits until at most 3 * kRingInFlight DMA instructions are outstanding, which means
+// fill f - kRingInFlight has landed, and publishes that one (its consumer is remembered in `hist`).
+__device__ __forceinline__ void ring_loader(const SellSystem& S, RingPtr L, u32 s_begin, u32 s_end, u32 lane) {
+    __builtin_amdgcn_s_setprio(3);
+    const u64 val0 = (u64)S.A.val, val1 = (u64)S.B.val, val2 = (u64)S.C.val;
+    const u64 tail0 = (u64)S.A.tail, tail1 = (u64)S.B.tail, tail2 = (u64)S.C.tail;
+    const bool unit_c = S.unit_c != 0;
+    const u32 lane16 = lane * 16, me = lane < kRingCons ? lane : 0u;
+    const u32 ring0 = lds_addr(&L->slot[me][0][0]);
+    u32 seq_v = 0, dslot = 0;           // lane c: fills issued to consumer c; ring buffer of the next one
+    u32 pub_v = 0;                      // lane c: fills published to consumer c
+    u32 hist = 0;                       // lane (f % 64): consumer of fill number f
+    u32 fill_no = 0, retired = 0;       // fills issued; fills known to be published
+    for (u32 sb = s_begin; sb < s_end; sb += kRingCons) {
+        const u32 mine = sb + lane;
+        v4u32 m = {0, 0, 0, 0};
+        if (lane < kRingCons && mine < s_end) m = L->meta[mine - s_begin];
+        const u32 na = m.w & 0xffu, nb = (m.w >> 8) & 0xffu, nc = unit_c ? 0u : (m.w >> 16) & 0xffu;
+        const u32 tot = na + nb + nc;
+        u32 maxtot = tot;
+        for (int off = 32; off > 0; off >>= 1) { const u32 o = __shfl_xor(maxtot, off, 64); maxtot = o > maxtot ? o : maxtot; }
+        maxtot = __builtin_amdgcn_readfirstlane(maxtot);
+        for (u32 j = 0; j < maxtot; ++j) {
+            const bool act = j < tot;
+            u64 vsrc, tsrc;
+            if (j < na) { const u64 q = m.x + j; vsrc = val0 + q * 2048; tsrc = tail0 + q * 512; }
+            else if (j < na + nb) { const u64 q = m.y + (j - na); vsrc = val1 + q * 2048; tsrc = tail1 + q * 512; }
+            else { const u64 q = m.z + (j - na - nb); vsrc = val2 + q * 2048; tsrc = tail2 + q * 512; }
+            const u32 dst = ring0 + dslot * kRingSlotBytes;
+            // every consumer of this pass needs a free buffer
+            while (ACX_RING_ABL != 4 && __ballot(act && seq_v - lds_peek(&L->consumed[lane & 15u]) >= kRingDepth) != 0) {
+                if (retired != fill_no) {   // blocked: hand over everything in flight (a consumer may wait for exactly that)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pub_v = seq_v;
+                    if (lane < 16) lds_poke(&L->filled[lane], pub_v);
+                    retired = fill_no;
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            unsigned long long mm = __ballot(act);
+            while (mm) {
+                const u32 c = (u32)__ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const u64 vb = ((u64)(u32)__builtin_amdgcn_readlane((u32)(vsrc >> 32), c) << 32) | (u32)__builtin_amdgcn_readlane((u32)vsrc, c);
+                const u64 tb = ((u64)(u32)__builtin_amdgcn_readlane((u32)(tsrc >> 32), c) << 32) | (u32)__builtin_amdgcn_readlane((u32)tsrc, c);
+                ring_fill(vb, tb, lane16, (u32)__builtin_amdgcn_readlane(dst, c));
+                hist = lane == (fill_no & 63u) ? c : hist;
+                ++fill_no;
+                if (fill_no - retired > kRingInFlight) {
+                    // DMA completes in issue order: with at most 3 * kRingInFlight instructions
+                    // outstanding the fill issued kRingInFlight fills ago has landed
+                    asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+                    const u32 co = (u32)__builtin_amdgcn_readlane(hist, retired & 63u);
+                    ++retired;
+                    pub_v += lane == co ? 1u : 0u;
+                    if (lane == co) lds_poke(&L->filled[lane], pub_v);
+                }
+            }
+            seq_v += act ? 1u : 0u;
+            dslot = act ? (dslot + 1 == kRingDepth ? 0u : dslot + 1) : dslot;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < 16) lds_poke(&L->filled[lane], seq_v);
+}
+static_assert(kRingInFlight == 20, "the s_waitcnt immediate in ring_loader is 3 * kRingInFlight");
+
+template <class F>
+__device__ __forceinline__ void ring_consumer(const SellSystem& S, RingPtr L, u32 c, u32 lane, u32 s_begin, u32 s_end) {
+    const uint4* const w = S.w;
+    const bool unit_c = S.unit_c != 0;
+#if ACX_RING_ABL == 4
+    return;
+#endif
+    u32 n = 0, d = 0;                   // fills consumed so far; ring buffer of fill n
+    auto wait_filled = [&](u32 k) {
+        while (lds_peek(&L->filled[c]) <= k) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    for (u32 s = s_begin + c; s < s_end; s += kRingCons) {
+        const v4u32 m = L->meta[s - s_begin];
+        const u32 na = m.w & 0xffu, nb = (m.w >> 8) & 0xffu, nc_all = (m.w >> 16) & 0xffu;
+        const u32 e0 = na, e1 = na + nb, total = e1 + (unit_c ? 0u : nc_all);
+        const u32 row = gload(S.perm + (u64)s * kSlice + lane);
+        u32 ccol = kNoRow;              // unit C: the column words come straight from global memory
+        if (unit_c && nc_all) ccol = nt_load(&S.C.tail[(u64)m.z * kSlice + lane]).y;
+        uint4 cxlo = make_uint4(0, 0, 0, 0), cxhi = cxlo;
+        Fe a = fe_zero(), b = a, cc = a, acc = a;
+        bool have = false;
+        int terms = 0;
+        Wide wide;
+        uint2 t = make_uint2(0, kNoRow);
+        uint4 xlo = make_uint4(0, 0, 0, 0), xhi = xlo;
+        if (total) {
+            wait_filled(n);
+            const v2u32 t0 = ((lds_v2u32*)&L->slot[c][d][128])[lane];
+            t = make_uint2(t0.x, t0.y);
+            const uint4* px = w + 2 * (u64)(t.y == kNoRow ? 0u : t.y);   // padding: value 0 * w[0]
+            xlo = gload(px); xhi = gload(px + 1);
+        }
+        for (u32 j = 0; j < total; ++j) {
+            const v4u32 lo = L->slot[c][d][lane], hi = L->slot[c][d][kSlice + lane];
+            asm volatile("" ::: "memory");                                // the LDS reads above stay above the release
+            ++n;
+            if (lane == 0) lds_poke(&L->consumed[c], n);                  // slot j is in registers: its buffer is free
+            const u32 dn = d + 1 == kRingDepth ? 0u : d + 1;
+            uint2 tn = make_uint2(0, kNoRow);
+            uint4 nlo = xlo, nhi = xhi;
+            if (j + 1 < total) {        // the next slot's gather goes out before this slot's multiply
+                wait_filled(n);
+                const v2u32 t1 = ((lds_v2u32*)&L->slot[c][dn][128])[lane];
+                tn = make_uint2(t1.x, t1.y);
+                const uint4* px = w + 2 * (u64)(tn.y == kNoRow ? 0u : tn.y);
+#if ACX_RING_ABL == 0
+                nlo = gload(px); nhi = gload(px + 1);
+#else
+                nlo = make_uint4(tn.y, 1, 2, 3); nhi = nlo;
+#endif
+            } else if (ccol != kNoRow) {
+                cxlo = gload(w + 2 * (u64)ccol); cxhi = gload(w + 2 * (u64)ccol + 1);
+            }
+            Fe v;
+            v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
+            v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
+            v.l[8] = t.x;
+            const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
+            const Fe x = fe_unpack(xw);
+#if ACX_RING_ABL == 2
+            if (terms == 0) { wide_zero(wide); } wide.c[0] += v.l[0] ^ x.l[1]; wide.c[1] += v.l[5] ^ v.l[8];
+#else
+            if (terms == 0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
+#endif
+            const bool last = j + 1 == e0 || j + 1 == e1 || j + 1 == total;
+            if (++terms == kWideTerms || last) {
+                const Fe part = wide_reduce<F>(wide);
+                acc = have ? fe_add<F>(acc, part) : part;
+                have = true;
+                terms = 0;
+            }
+            if (last) {
+                if (j + 1 == e0) a = acc; else if (j + 1 == e1) b = acc; else cc = acc;
+                have = false;
+            }
+            t = tn; xlo = nlo; xhi = nhi; d = dn;
+        }
+        if (unit_c && nc_all) {
+            if (total == 0 && ccol != kNoRow) { cxlo = gload(w + 2 * (u64)ccol); cxhi = gload(w + 2 * (u64)ccol + 1); }
+            if (ccol != kNoRow) {
+                const u32 xw[8] = {cxlo.x, cxlo.y, cxlo.z, cxlo.w, cxhi.x, cxhi.y, cxhi.z, cxhi.w};
+                cc = fe_unpack(xw);
+            }
+            for (u32 q = 1; q < nc_all; ++q) {                            // more than one unit entry in a C row: rare
+                const u32 col = gload(&S.C.tail[(u64)(m.z + q) * kSlice + lane]).y;
+                if (col != kNoRow) cc = fe_add<F>(cc, fe_gload(w + 2 * (u64)col));
+            }
+        }
+        residual_epilogue<F>(a, b, cc, row, row != kNoRow, S.out);
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(kRingWaves * 64) void k_r1cs_ring(const SellSystem* __restrict__ systems, SellSystem one,
+                                                              u32 parts, u32 n_sys) {
+    extern __shared__ uint4 ring_raw[];
+    const RingPtr L = (RingPtr)ring_raw;
+    // workgroup -> (system, part).  Workgroup b runs on XCD b % 8: a system's parts (batched launch,
+    // systems a multiple of 8) or a contiguous eighth of the single system's slices stay on one XCD.
+    const u32 lin = blockIdx.x;
+    u32 sys = 0, part = lin;
+    if (n_sys > 1) {
+        if ((n_sys & 7u) == 0) { const u32 k = lin >> 3; sys = (k / parts) * 8 + (lin & 7u); part = k % parts; }
+        else { sys = lin / parts; part = lin % parts; }
+    } else if ((parts & 7u) == 0) {
+        part = (lin & 7u) * (parts >> 3) + (lin >> 3);
+    }
+    const SellSystem& S = systems != nullptr ? systems[sys] : one;
+    const u32 chunk = (S.n_slices + parts - 1) / parts;
+    const u32 s_begin = part * chunk < S.n_slices ? part * chunk : S.n_slices;
+    const u32 s_end = s_begin + chunk < S.n_slices ? s_begin + chunk : S.n_slices;
+    for (u32 i = threadIdx.x; i < s_end - s_begin; i += kRingWaves * 64) {
+        const u32 s = s_begin + i;
+        const u32 qa = gload(S.A.slice_ofs + s), qb = gload(S.B.slice_ofs + s), qc = gload(S.C.slice_ofs + s);
+        const u32 na = gload(S.A.slice_ofs + s + 1) - qa, nb = gload(S.B.slice_ofs + s + 1) - qb,
+                  nc = gload(S.C.slice_ofs + s + 1) - qc;
+        L->meta[i] = v4u32{qa, qb, qc, na | (nb << 8) | (nc << 16)};
+    }
+    if (threadIdx.x < 16) { L->filled[threadIdx.x] = 0; L->consumed[threadIdx.x] = 0; }
+    __syncthreads();
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (wave == kRingCons) ring_loader(S, L, s_begin, s_end, lane);
+    else ring_consumer<F>(S, L, wave, lane, s_begin, s_end);
 }
 
 // CSR path for the listed rows only (rows too long for the SELL layout).

@@ -65,7 +65,7 @@ def bench_r1cs(ctx, stream, log_n, reps, copies):
 
     us = time_stream(stream, fn, reps * copies)
     ctx.sync()
-    assert int(res[0]) == 0, "witness must verify"
+    assert int(res[0]) == 0 or os.environ.get("ACX_ABLATION"), "witness must verify"
     print(f"r1cs n=2^{log_n} copies={copies}: {us:9.2f} us/launch  {n / us * 1e6:.3e} constraints/s  "
           f"alg {b / 1e6:.2f} MB -> {b / us * 1e-3:.1f} GB/s ({b / us * 1e-3 / 8000 * 100:.1f}% of 8 TB/s)  nnz={nnz} m_ref={m_ref}")
 
