@@ -384,12 +384,21 @@ inline unsigned sell_grid_x(uint32_t n_slices) {
 // The producer/consumer kernel (k_r1cs_ring) needs its 129 KiB of dynamic LDS enabled once per
 // instantiation, and pays off only when the launch fills the chip: one workgroup per CU, every
 // consumer wave with several slices to walk.
-constexpr uint32_t kRingMinSlices = 0xffffffffu;   // experimental (profiles/r01_r1cs_ring.txt): not selected yet
+constexpr uint32_t kRingMinSlices = 0xffffffffu;   // experimental, never selected
+#ifndef ACX_RING_NW
+#define ACX_RING_NW 16
+#define ACX_RING_NL 4
+#define ACX_RING_D 4
+#define ACX_RING_G 2
+#endif
+constexpr int kRingWaves = ACX_RING_NW, kRingLoaders = ACX_RING_NL, kRingDepth = ACX_RING_D, kRingGather = ACX_RING_G;
+using RingLdsT = RingLds<kRingWaves - kRingLoaders, kRingDepth>;
+#define K_R1CS_RING k_r1cs_ring<F, kRingWaves, kRingLoaders, kRingDepth, kRingGather>
 inline bool ring_ready(acx_ctx* c) {
     if (c->ring_state == 0) {
         hipError_t e = hipSuccess;
-        DISPATCH_FIELD(c, e = hipFuncSetAttribute((const void*)k_r1cs_ring<F>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)sizeof(RingLds)));
+        DISPATCH_FIELD(c, e = hipFuncSetAttribute((const void*)K_R1CS_RING, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)sizeof(RingLdsT)));
         c->ring_state = e == hipSuccess ? 1 : -1;
         (void)hipGetLastError();
     }
@@ -428,7 +437,7 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
     const SellSystem S = sell_system(r, d_w, out);
     if (r->n_slices >= kRingMinSlices && ring_ready(c)) {
         const uint32_t parts = ring_parts((uint32_t)c->n_cu, r->n_slices, 1);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_ring<F>), dim3(parts), dim3(kRingWaves * 64), sizeof(RingLds), c->stream,
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((K_R1CS_RING), dim3(parts), dim3(kRingWaves * 64), sizeof(RingLdsT), c->stream,
                                              (const SellSystem*)nullptr, S, parts, 1u));
     } else {
         const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
@@ -480,6 +489,7 @@ int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
                 const uint32_t row = perm[(size_t)s * kSlice + l];
                 if (row != kNoRow) mx = std::max(mx, rowptr[k][row + 1] - rowptr[k][row]);
             }
+            if (k == 0 && mx == 0) mx = 1;      // k_r1cs_ring wants >= 1 slot per slice (the last one carries the row indices)
             ofs[s + 1] = ofs[s] + mx;
         }
         const uint64_t slots = ofs[n_slices];
@@ -1452,7 +1462,7 @@ int acx_batch_verify_dev(acx_batch* b) {
         const uint32_t n_sys = (uint32_t)b->systems.size();
         if (b->total_slices >= kRingMinSlices && ring_ready(c)) {
             const uint32_t parts = ring_parts((uint32_t)c->n_cu, b->max_slices, n_sys);
-            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_ring<F>), dim3(parts * n_sys), dim3(kRingWaves * 64), sizeof(RingLds),
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((K_R1CS_RING), dim3(parts * n_sys), dim3(kRingWaves * 64), sizeof(RingLdsT),
                                                  c->stream, (const SellSystem*)b->d_systems, SellSystem{}, parts, n_sys));
         } else {
             const dim3 grid(sell_grid_x(b->max_slices), n_sys, 1);
