@@ -58,7 +58,6 @@ struct acx_ctx {
     unsigned long long* d_result = nullptr;                // {n_bad, first_bad}
     uint32_t* d_err = nullptr;
     int n_cu = 256;
-    int ring_state = 0;                                    // k_r1cs_ring dynamic-LDS attribute: 0 unset, 1 ok, -1 unavailable
 };
 
 struct DevMatrix {
@@ -101,7 +100,6 @@ struct acx_batch {
     std::vector<ResidualOut> outs;
     SellSystem* d_systems = nullptr;
     uint32_t max_slices = 0;
-    uint64_t total_slices = 0;
 };
 
 struct acx_naive {          // createPolynomials state for arbitrary distinct roots (n <= 4096)
@@ -381,37 +379,6 @@ inline unsigned sell_grid_x(uint32_t n_slices) {
     return ((tiles + 7) / 8) * 8;   // multiple of 8: the XCD remap is a bijection
 }
 
-// The producer/consumer kernel (k_r1cs_ring) needs its 129 KiB of dynamic LDS enabled once per
-// instantiation, and pays off only when the launch fills the chip: one workgroup per CU, every
-// consumer wave with several slices to walk.
-constexpr uint32_t kRingMinSlices = 0xffffffffu;   // experimental, never selected
-#ifndef ACX_RING_NW
-#define ACX_RING_NW 16
-#define ACX_RING_NL 4
-#define ACX_RING_D 4
-#define ACX_RING_G 2
-#endif
-constexpr int kRingWaves = ACX_RING_NW, kRingLoaders = ACX_RING_NL, kRingDepth = ACX_RING_D, kRingGather = ACX_RING_G;
-using RingLdsT = RingLds<kRingWaves - kRingLoaders, kRingDepth>;
-#define K_R1CS_RING k_r1cs_ring<F, kRingWaves, kRingLoaders, kRingDepth, kRingGather>
-inline bool ring_ready(acx_ctx* c) {
-    if (c->ring_state == 0) {
-        hipError_t e = hipSuccess;
-        DISPATCH_FIELD(c, e = hipFuncSetAttribute((const void*)K_R1CS_RING, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)sizeof(RingLdsT)));
-        c->ring_state = e == hipSuccess ? 1 : -1;
-        (void)hipGetLastError();
-    }
-    return c->ring_state > 0;
-}
-// workgroups per system for a launch of n_sys systems whose largest has max_slices slices
-inline uint32_t ring_parts(uint32_t n_cu, uint32_t max_slices, uint32_t n_sys) {
-    uint32_t parts = std::max<uint32_t>(1, n_cu / std::max<uint32_t>(n_sys, 1));   // one workgroup per CU
-    parts = std::max(parts, (max_slices + kRingMaxChunk - 1) / kRingMaxChunk);
-    if (n_sys == 1) parts = (parts + 7) / 8 * 8;
-    return parts;
-}
-
 // rows too long for SELL go through the CSR kernel
 int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out) {
     acx_ctx* c = r->ctx;
@@ -435,15 +402,9 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
     if (r->n == 0) return ACX_OK;
     const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset};
     const SellSystem S = sell_system(r, d_w, out);
-    if (r->n_slices >= kRingMinSlices && ring_ready(c)) {
-        const uint32_t parts = ring_parts((uint32_t)c->n_cu, r->n_slices, 1);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((K_R1CS_RING), dim3(parts), dim3(kRingWaves * 64), sizeof(RingLdsT), c->stream,
-                                             (const SellSystem*)nullptr, S, parts, 1u));
-    } else {
-        const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, c->stream,
-                                             (const SellSystem*)nullptr, S));
-    }
+    const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, c->stream,
+                                         (const SellSystem*)nullptr, S));
     HIP_TRY(hipGetLastError());
     return launch_long_rows(r, d_w, out);
 }
@@ -489,7 +450,6 @@ int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
                 const uint32_t row = perm[(size_t)s * kSlice + l];
                 if (row != kNoRow) mx = std::max(mx, rowptr[k][row + 1] - rowptr[k][row]);
             }
-            if (k == 0 && mx == 0) mx = 1;      // k_r1cs_ring wants >= 1 slot per slice (the last one carries the row indices)
             ofs[s + 1] = ofs[s] + mx;
         }
         const uint64_t slots = ofs[n_slices];
@@ -1431,7 +1391,6 @@ int acx_batch_create(acx_ctx* ctx, uint64_t count, acx_r1cs* const* systems, con
         b->witnesses.push_back((const uint4*)d_witnesses[i]);
         b->outs.push_back(o);
         b->max_slices = std::max(b->max_slices, r->n_slices);
-        b->total_slices += r->n_slices;
         row_offset += r->n;
     }
     if (hipMalloc((void**)&b->d_systems, count * sizeof(SellSystem)) != hipSuccess) { delete b; return fail(ACX_ERR_OOM, "device allocation failed"); }
@@ -1459,16 +1418,9 @@ int acx_batch_verify_dev(acx_batch* b) {
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     if (b->max_slices) {
-        const uint32_t n_sys = (uint32_t)b->systems.size();
-        if (b->total_slices >= kRingMinSlices && ring_ready(c)) {
-            const uint32_t parts = ring_parts((uint32_t)c->n_cu, b->max_slices, n_sys);
-            DISPATCH_FIELD(c, hipLaunchKernelGGL((K_R1CS_RING), dim3(parts * n_sys), dim3(kRingWaves * 64), sizeof(RingLdsT),
-                                                 c->stream, (const SellSystem*)b->d_systems, SellSystem{}, parts, n_sys));
-        } else {
-            const dim3 grid(sell_grid_x(b->max_slices), n_sys, 1);
-            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, c->stream,
-                                                 (const SellSystem*)b->d_systems, SellSystem{}));
-        }
+        const dim3 grid(sell_grid_x(b->max_slices), (unsigned)b->systems.size(), 1);
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, c->stream,
+                                             (const SellSystem*)b->d_systems, SellSystem{}));
         HIP_TRY(hipGetLastError());
     }
     for (size_t i = 0; i < b->systems.size(); ++i)

@@ -228,9 +228,6 @@ __device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, cons
         }
     }
     const unsigned long long mask = __ballot(bad);
-#if defined(ACX_RING_ABL) && ACX_RING_ABL != 0
-    if (mask != 12345) return;                               // ablation builds compute garbage: no result atomics
-#endif
     if (mask == 0) return;                                   // wave-uniform
     unsigned long long my_first = bad ? (u64)row + out.row_offset : ~0ull;
     for (int off = 32; off > 0; off >>= 1) {
@@ -278,386 +275,6 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
         c = S.unit_c ? sell_dot<F, true>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
     }
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
-}
-
-#ifndef ACX_RING_ABL
-#define ACX_RING_ABL 0
-#endif
-// ---- K2r: producer/consumer form of K2 for large launches -------------------------------------
-// PMC view of K2 (tools/prof.py tcp1/tcp2, profiles/r01_r1cs_ring.txt): the CU's L1 (TCP) is busy
-// 86 % of the time with only ~56 misses outstanding, and it returns data in request order, so an
-// L2-resident witness gather queues behind the HBM stream loads of the same CU and takes ~2 us.
-// With one gather per wave in flight K2 is bound by (waves x 2 KB) / gather latency.  K2r raises
-// the number of gathers in flight:
-//   * one LOADER wave per workgroup streams every SELL slot of the workgroup's slices (A, B and C,
-//     plus the slice's row indices with its last slot) into per-consumer LDS rings with global->LDS
-//     DMA (global_load_lds_dwordx4: no VGPRs, ~50 KB in flight per CU whatever the other waves do);
-//   * NC CONSUMER waves take column words, value limbs and row indices from LDS, so their only
-//     vector-memory loads are witness gathers.  A consumer walks its slots as one sequence across
-//     slice boundaries and keeps G gathers in flight (slot n + G - 1 is requested before slot n is
-//     multiplied); with few waves per workgroup it has the registers for that.  The slot loop is
-//     unrolled G times with the register set of every step fixed at compile time, and a gather is
-//     issued in EVERY step (a dummy one to w[0] when the sequence is exhausted), so hipcc's
-//     s_waitcnt vmcnt analysis is exact: 2 * (G - 1) loads are younger than the one being consumed.
-//   ring slot   = 2 KiB value limbs 0-7 (two 1 KiB planes) + 512 B {limb 8, column} + 256 B row indices
-//   filled[c]   = slots published to consumer c (written by the loader after the DMA landed)
-//   consumed[c] = slots consumer c has copied out of LDS (the loader reuses a buffer after that)
-// One workgroup = one CU; grid = parts x systems.  Requires >= 1 slot per slice (build_sell pads A).
-constexpr u32 kRingSlotBytes = 2816;
-constexpr u32 kRingMaxChunk = 512;      // slices per workgroup (one 16-byte metadata record each)
-
-template <int NC, int D>
-struct RingLds {
-    v4u32 slot[NC][D][kRingSlotBytes / 16];
-    v4u32 meta[kRingMaxChunk];          // {first A slot, first B slot, first C slot, nA | nB << 8 | nC << 16}
-    u32 filled[16];
-    u32 consumed[16];
-};
-// Every access goes through an LDS-address-space pointer: through a generic pointer hipcc emits
-// flat loads/stores, and a volatile flat store is followed by s_waitcnt vmcnt(0) -- which would
-// wait for every DMA (loader) or gather (consumer) in flight each time a flag is written.
-#define ACX_LDS __attribute__((address_space(3)))
-typedef ACX_LDS const v2u32 lds_v2u32;
-typedef ACX_LDS const u32 lds_u32;
-
-__device__ __forceinline__ u32 lds_addr(const ACX_LDS void* p) { return (u32)(uintptr_t)p; }
-__device__ __forceinline__ u32 lds_peek(const ACX_LDS u32* p) { return *(const volatile ACX_LDS u32*)p; }
-__device__ __forceinline__ void lds_poke(ACX_LDS u32* p, u32 v) { *(volatile ACX_LDS u32*)p = v; }
-
-// One ring fill = three DMA instructions (every lane moves 16 bytes to lds_byte + 16 * lane):
-//   1,2: value limbs, 1 KiB each at +0 / +1024 (the instruction offset applies to the LDS address as
-//        well as to the global one); for a unit-coefficient slot only lane 0 runs (val_exec = 1) --
-//        the values are not needed but every fill must count three in vmcnt;
-//   3:   per-lane addresses: lanes 0-31 the 512 B of {limb 8, column} at +2048, lanes 32-47 the
-//        slice's 256 B of row indices at +2560 when this is the slice's last slot (tail_exec).
-// Hand-issued: hipcc does not see the DMA, so it neither reserves VGPRs nor waits for it before
-// later LDS reads; completion is tracked with the explicit s_waitcnt vmcnt in ring_loader.
-__device__ __forceinline__ void ring_fill(u64 val_base, u64 val_exec, u64 tail_addr, u64 tail_exec, u32 lane16, u32 lds_byte) {
-    u32 keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %6\n\t"
-        "s_mov_b64 exec, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "s_add_u32 m0, %6, 0x800\n\t"
-        "s_mov_b64 exec, %5\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, off\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(lane16), "s"(val_base), "s"(val_exec), "v"(tail_addr), "s"(tail_exec), "s"(lds_byte) : "memory", "scc");
-}
-
-// The loader works in PASSES: pass j of a round issues slot j of every consumer's current slice
-// (<= NC fills).  All per-consumer bookkeeping is lane-parallel (lane c = consumer c); only the DMA
-// issue itself loops over the consumers.  kRingInFlight fills stay in flight: after issuing fill f
-// the loader waits until at most 3 * kRingInFlight DMA instructions are outstanding, which means
-// fill f - kRingInFlight has landed, and publishes that one (its consumer is remembered in `hist`).
-#ifdef ACX_RING_DEBUG
-#define ACX_T0(v) const u64 v = __builtin_amdgcn_s_memtime()
-#define ACX_TACC(acc, v) acc += __builtin_amdgcn_s_memtime() - v
-#else
-#define ACX_T0(v)
-#define ACX_TACC(acc, v)
-#endif
-template <int NC, int D, int NL>
-__device__ __forceinline__ void ring_loader(const SellSystem& S, ACX_LDS RingLds<NC, D>* L, u32 s_begin, u32 s_end, u32 lane, u32 li, u64* dbg) {
-    // fills this loader keeps in flight (3 DMA instructions each; vmcnt counts to 63)
-    constexpr u32 kInFlight = NL == 1 ? 20 : (NL == 2 ? 10 : 5);
-    __builtin_amdgcn_s_setprio(3);
-    u64 t_space = 0, t_vm = 0, n_block = 0;
-    ACX_T0(t_all);
-    const u64 val0 = (u64)S.A.val, val1 = (u64)S.B.val, val2 = (u64)S.C.val;
-    const u64 tail0 = (u64)S.A.tail, tail1 = (u64)S.B.tail, tail2 = (u64)S.C.tail;
-    const u64 perm0 = (u64)S.perm;
-    const bool unit_c = S.unit_c != 0;
-    const u32 lane16 = lane * 16, me = lane < (u32)NC ? lane : 0u;
-    const u32 ring0 = lds_addr(&L->slot[me][0][0]);
-    u32 seq_v = 0, dslot = 0;           // lane c: fills issued to consumer c; ring buffer of the next one
-    u32 pub_v = 0;                      // lane c: fills published to consumer c
-    u32 hist = 0;                       // lane (f % 64): consumer of fill number f
-    u32 fill_no = 0, retired = 0;       // fills issued; fills known to be published
-    for (u32 sb = s_begin; sb < s_end; sb += NC) {
-        const u32 mine = sb + lane;
-        v4u32 m = {0, 0, 0, 0};
-        if (lane < (u32)NC && lane % NL == li && mine < s_end) m = L->meta[mine - s_begin];   // this loader's consumers only
-        const u32 na = m.w & 0xffu, nb = (m.w >> 8) & 0xffu, nc = (m.w >> 16) & 0xffu;
-        const u32 tot = na + nb + nc;
-        u32 maxtot = tot;
-        for (int off = 32; off > 0; off >>= 1) { const u32 o = __shfl_xor(maxtot, off, 64); maxtot = o > maxtot ? o : maxtot; }
-        maxtot = __builtin_amdgcn_readfirstlane(maxtot);
-        for (u32 j = 0; j < maxtot; ++j) {
-            const bool act = j < tot;
-            u64 vsrc, tsrc;
-            u32 flags = (j + 1 == tot) ? 1u : 0u;       // bit 0: the slice's last slot (carries the row indices)
-            if (j < na) { const u64 q = m.x + j; vsrc = val0 + q * 2048; tsrc = tail0 + q * 512; }
-            else if (j < na + nb) { const u64 q = m.y + (j - na); vsrc = val1 + q * 2048; tsrc = tail1 + q * 512; }
-            else { const u64 q = m.z + (j - na - nb); vsrc = val2 + q * 2048; tsrc = tail2 + q * 512; flags |= unit_c ? 2u : 0u; }
-            const u64 psrc = perm0 + (u64)mine * (kSlice * 4);
-            const u32 dst = ring0 + dslot * kRingSlotBytes;
-            // every consumer of this pass needs a free buffer
-            ACX_T0(t_s);
-            while (ACX_RING_ABL != 4 && __ballot(act && seq_v - lds_peek(&L->consumed[lane & 15u]) >= (u32)D) != 0) {
-                if (retired != fill_no) {   // blocked: hand over everything in flight (a consumer may wait for exactly that)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    pub_v = seq_v;
-                    if (lane < (u32)NC && lane % NL == li) lds_poke(&L->filled[lane], pub_v);
-                    retired = fill_no;
-                    ++n_block;
-                } else {
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            ACX_TACC(t_space, t_s);
-            unsigned long long mm = __ballot(act);
-            while (mm) {
-                const u32 c = (u32)__ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                const u64 vb = ((u64)(u32)__builtin_amdgcn_readlane((u32)(vsrc >> 32), c) << 32) | (u32)__builtin_amdgcn_readlane((u32)vsrc, c);
-                const u64 tb = ((u64)(u32)__builtin_amdgcn_readlane((u32)(tsrc >> 32), c) << 32) | (u32)__builtin_amdgcn_readlane((u32)tsrc, c);
-                const u64 pb = ((u64)(u32)__builtin_amdgcn_readlane((u32)(psrc >> 32), c) << 32) | (u32)__builtin_amdgcn_readlane((u32)psrc, c);
-                const u32 fl = (u32)__builtin_amdgcn_readlane(flags, c);
-                const u64 taddr = lane < 32 ? tb + lane16 : pb + (lane16 - 512);
-                ring_fill(vb, (fl & 2u) ? 1ull : ~0ull, taddr, (fl & 1u) ? 0x0000ffffffffffffull : 0x00000000ffffffffull, lane16,
-                          (u32)__builtin_amdgcn_readlane(dst, c));
-                hist = lane == (fill_no & 63u) ? c : hist;
-                ++fill_no;
-                if (fill_no - retired > kInFlight) {
-                    // DMA completes in issue order: with at most 3 * kInFlight instructions
-                    // outstanding the fill issued kInFlight fills ago has landed
-                    ACX_T0(t_v);
-                    if (kInFlight == 20) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
-                    else if (kInFlight == 10) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-                    ACX_TACC(t_vm, t_v);
-                    const u32 co = (u32)__builtin_amdgcn_readlane(hist, retired & 63u);
-                    ++retired;
-                    pub_v += lane == co ? 1u : 0u;
-                    if (lane == co) lds_poke(&L->filled[lane], pub_v);
-                }
-            }
-            seq_v += act ? 1u : 0u;
-            dslot = act ? (dslot + 1 == (u32)D ? 0u : dslot + 1) : dslot;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane < (u32)NC && lane % NL == li) lds_poke(&L->filled[lane], seq_v);
-#ifdef ACX_RING_DEBUG
-    if (dbg && lane == 0) {
-        u64* o = dbg + ((u64)blockIdx.x * 16 + NC + li) * 4;
-        o[0] = __builtin_amdgcn_s_memtime() - t_all; o[1] = t_space; o[2] = t_vm; o[3] = ((u64)fill_no << 32) | n_block;
-    }
-#endif
-}
-
-// State of one consumer wave.  A struct with force-inlined member templates instead of lambdas:
-// hipcc keeps by-reference lambda captures in scratch memory when the step is instantiated G times.
-template <class F, int NC, int D, int G>
-struct RingConsumer {
-    static_assert(D >= G + 1, "the ring holds the G slots whose gathers are in flight plus one being filled");
-    static_assert(G >= 2 && G <= 6, "the unrolled steps are written out for 2 <= G <= 6");
-    ACX_LDS RingLds<NC, D>* L;
-    const uint4* w;
-    ResidualOut out;
-    u32 c, lane, s_begin, s_end;
-    bool unit_c;
-    // lookahead cursor: the next slot of this consumer's sequence whose gather goes out
-    u32 la_s, la_left, la_n, la_d;
-    // processing cursor
-    u32 ps, pj, pe0, pe1, ptot, n, d;
-    // register sets of the gathers in flight
-    v4u32 gxl[G], gxh[G];              // plain vectors: arrays of HIP's uint4 run constructors in a loop and end up in scratch
-    u32 l8[G], colv[G];
-    // row accumulators
-    Fe a, b, cc, acc;
-    Wide wide;
-    bool have;
-    int terms;
-    u64 t_fill = 0, t_gather = 0;
-
-    __device__ __forceinline__ u32 slots_of(u32 s) const {
-        const v4u32 m = L->meta[s - s_begin];
-        return (m.w & 0xffu) + ((m.w >> 8) & 0xffu) + ((m.w >> 16) & 0xffu);
-    }
-    __device__ __forceinline__ void load_slice() {
-        const v4u32 m = L->meta[ps - s_begin];
-        pe0 = m.w & 0xffu; pe1 = pe0 + ((m.w >> 8) & 0xffu); ptot = pe1 + ((m.w >> 16) & 0xffu);
-    }
-    template <int K>
-    __device__ __forceinline__ void issue() {
-        u32 col = kNoRow, limb = 0;
-        if (la_s < s_end) {
-            ACX_T0(t_w);
-            while (lds_peek(&L->filled[c]) <= la_n) __builtin_amdgcn_s_sleep(1);
-            ACX_TACC(t_fill, t_w);
-            asm volatile("" ::: "memory");
-            const v2u32 t = ((lds_v2u32*)&L->slot[c][la_d][128])[lane];
-            limb = t.x; col = t.y;
-            ++la_n;
-            la_d = la_d + 1 == (u32)D ? 0u : la_d + 1;
-            if (--la_left == 0) {
-                la_s += NC;
-                if (la_s < s_end) la_left = slots_of(la_s);
-            }
-        }
-        l8[K] = limb; colv[K] = col;
-        const uint4* px = w + 2 * (u64)(col == kNoRow ? 0u : col);       // padding / exhausted: w[0], never used
-#if ACX_RING_ABL != 0
-        px = w + (lane & 1u);
-#endif
-        gxl[K] = *(g_v4u32*)px; gxh[K] = *(g_v4u32*)(px + 1);
-    }
-    template <int K>
-    __device__ __forceinline__ bool step() {
-        issue<(K + G - 1) % G>();                   // slot n + G - 1 goes out before slot n is multiplied
-        const u32 kind = pj < pe0 ? 0u : (pj < pe1 ? 1u : 2u);
-        const bool unit = kind == 2u && unit_c;
-        const bool slice_end = pj + 1 == ptot;
-        const bool matrix_end = pj + 1 == pe0 || pj + 1 == pe1 || slice_end;
-        u32 row = kNoRow;
-        v4u32 lo = {0, 0, 0, 0}, hi = lo;
-        if (slice_end) row = ((lds_u32*)&L->slot[c][d][160])[lane];
-        if (!unit) { lo = L->slot[c][d][lane]; hi = L->slot[c][d][kSlice + lane]; }
-        asm volatile("" ::: "memory");                                    // the LDS reads above stay above the release
-        ++n;
-        if (lane == 0) lds_poke(&L->consumed[c], n);                      // slot is in registers: its buffer is free
-        d = d + 1 == (u32)D ? 0u : d + 1;
-#ifdef ACX_RING_DEBUG
-        {   // time until the gather of this slot has landed
-            ACX_T0(t_g);
-            asm volatile("" : "+v"(gxl[K]), "+v"(gxh[K]));
-            ACX_TACC(t_gather, t_g);
-        }
-#endif
-        const v4u32 xlo = gxl[K], xhi = gxh[K];
-        const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
-        const Fe x = fe_unpack(xw);
-        if (unit) {
-            if (colv[K] != kNoRow) cc = fe_add<F>(cc, x);
-        } else {
-            Fe v;
-            v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
-            v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
-            v.l[8] = l8[K];
-#if ACX_RING_ABL == 2
-            wide.c[0] += v.l[0] ^ x.l[1]; wide.c[1] += v.l[5] ^ v.l[8];
-#else
-            wide_mac(wide, v, x);
-#endif
-            if (++terms == kWideTerms || matrix_end) {
-                const Fe part = wide_reduce<F>(wide);
-                wide_zero(wide);
-                acc = have ? fe_add<F>(acc, part) : part;
-                have = true;
-                terms = 0;
-            }
-            if (matrix_end) {
-                // limb-wise selects: "if (kind == 0) a = acc; else ..." becomes ONE copy to a computed member
-                // offset, and a variable offset keeps the whole struct in scratch memory
-#pragma unroll
-                for (int i = 0; i < kLimbs; ++i) {
-                    a.l[i] = kind == 0u ? acc.l[i] : a.l[i];
-                    b.l[i] = kind == 1u ? acc.l[i] : b.l[i];
-                    cc.l[i] = kind == 2u ? acc.l[i] : cc.l[i];
-                }
-                have = false;
-            }
-        }
-        ++pj;
-        if (slice_end) {
-            residual_epilogue<F>(a, b, cc, row, row != kNoRow, out);
-            a = fe_zero(); b = a; cc = a;
-            ps += NC; pj = 0;
-            if (ps >= s_end) return false;
-            load_slice();
-        }
-        return true;
-    }
-    __device__ __forceinline__ void run() {
-        la_s = s_begin + c; la_n = 0; la_d = 0; la_left = slots_of(la_s);
-        ps = s_begin + c; pj = 0; n = 0; d = 0;
-        load_slice();
-        a = fe_zero(); b = a; cc = a; acc = a;
-        have = false; terms = 0;
-        wide_zero(wide);
-        issue<0>();                                 // prologue: G - 1 gathers ahead
-        if (G > 2) issue<1 % G>();
-        if (G > 3) issue<2 % G>();
-        if (G > 4) issue<3 % G>();
-        if (G > 5) issue<4 % G>();
-        for (;;) {
-            if (!step<0>()) break;
-            if (!step<1>()) break;
-            if (G > 2 && !step<2 % G>()) break;
-            if (G > 3 && !step<3 % G>()) break;
-            if (G > 4 && !step<4 % G>()) break;
-            if (G > 5 && !step<5 % G>()) break;
-        }
-    }
-};
-
-template <class F, int NC, int D, int G>
-__device__ __forceinline__ void ring_consumer(const SellSystem& S, ACX_LDS RingLds<NC, D>* L, u32 c, u32 lane, u32 s_begin, u32 s_end) {
-    if (ACX_RING_ABL == 4 || s_begin + c >= s_end) return;
-    RingConsumer<F, NC, D, G> R;
-#ifdef ACX_RING_DEBUG
-    const u64 t_all = __builtin_amdgcn_s_memtime();
-#endif
-    R.L = L; R.w = S.w; R.out = S.out; R.c = c; R.lane = lane; R.s_begin = s_begin; R.s_end = s_end;
-    R.unit_c = S.unit_c != 0;
-#ifdef ACX_RING_DEBUG
-    u64* dbg = (u64*)S.out.dots;
-    R.out.dots = nullptr;
-#endif
-    R.run();
-#ifdef ACX_RING_DEBUG
-    if (dbg && lane == 0) {
-        u64* o = dbg + ((u64)blockIdx.x * 16 + c) * 4;
-        o[0] = __builtin_amdgcn_s_memtime() - t_all; o[1] = R.t_fill; o[2] = R.t_gather; o[3] = R.n;
-    }
-#endif
-}
-
-// NW waves per workgroup, NL of them loaders (NL > 1: the last wave of every group of NW / NL, i.e.
-// with NL = 4 waves 3, 7, 11, 15, which the hardware places on one SIMD: their scalar bookkeeping then
-// does not queue behind the consumers' multiplies).  Loader li serves the consumers c with c % NL == li.
-template <class F, int NW, int NL, int D, int G>
-__global__ __launch_bounds__(NW * 64) void k_r1cs_ring(const SellSystem* __restrict__ systems, SellSystem one,
-                                                      u32 parts, u32 n_sys) {
-    constexpr int NC = NW - NL;
-    static_assert(NW % NL == 0, "loaders are spread evenly over the waves");
-    static_assert(NC <= 15, "filled/consumed hold 16 consumers");
-    extern __shared__ uint4 ring_raw[];
-    ACX_LDS RingLds<NC, D>* const L = (ACX_LDS RingLds<NC, D>*)ring_raw;
-    // workgroup -> (system, part).  Workgroup b runs on XCD b % 8: a system's parts (batched launch,
-    // systems a multiple of 8) or a contiguous eighth of the single system's slices stay on one XCD.
-    const u32 lin = blockIdx.x;
-    u32 sys = 0, part = lin;
-    if (n_sys > 1) {
-        if ((n_sys & 7u) == 0) { const u32 k = lin >> 3; sys = (k / parts) * 8 + (lin & 7u); part = k % parts; }
-        else { sys = lin / parts; part = lin % parts; }
-    } else if ((parts & 7u) == 0) {
-        part = (lin & 7u) * (parts >> 3) + (lin >> 3);
-    }
-    const SellSystem& S = systems != nullptr ? systems[sys] : one;
-    const u32 chunk = (S.n_slices + parts - 1) / parts;
-    const u32 s_begin = part * chunk < S.n_slices ? part * chunk : S.n_slices;
-    const u32 s_end = s_begin + chunk < S.n_slices ? s_begin + chunk : S.n_slices;
-    for (u32 i = threadIdx.x; i < s_end - s_begin; i += NW * 64) {
-        const u32 s = s_begin + i;
-        const u32 qa = gload(S.A.slice_ofs + s), qb = gload(S.B.slice_ofs + s), qc = gload(S.C.slice_ofs + s);
-        const u32 na = gload(S.A.slice_ofs + s + 1) - qa, nb = gload(S.B.slice_ofs + s + 1) - qb,
-                  nc = gload(S.C.slice_ofs + s + 1) - qc;
-        L->meta[i] = v4u32{qa, qb, qc, na | (nb << 8) | (nc << 16)};
-    }
-    if (threadIdx.x < 16) { L->filled[threadIdx.x] = 0; L->consumed[threadIdx.x] = 0; }
-    __syncthreads();
-    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    constexpr u32 kGroup = NW / NL;
-    if (wave % kGroup == kGroup - 1) ring_loader<NC, D, NL>(S, L, s_begin, s_end, lane, wave / kGroup, (u64*)S.out.dots);
-    else ring_consumer<F, NC, D, G>(S, L, wave - wave / kGroup, lane, s_begin, s_end);
 }
 
 // CSR path for the listed rows only (rows too long for the SELL layout).

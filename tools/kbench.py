@@ -65,21 +65,6 @@ def bench_r1cs(ctx, stream, log_n, reps, copies):
 
     us = time_stream(stream, fn, reps * copies)
     ctx.sync()
-    if os.environ.get("ACX_RING_DEBUG"):      # library built with -DACX_RING_DEBUG: per-wave s_memtime breakdown
-        dbg = torch.zeros(4096 * 16 * 4, dtype=torch.int64, device="cuda")
-        r, w, _ = systems[0]
-        r.verify_dev(w.data_ptr(), res.data_ptr(), d_dots=dbg.data_ptr())
-        ctx.sync()
-        d = dbg.cpu().numpy().reshape(4096, 16, 4)
-        used = d[:, :, 0].any(axis=1)
-        d = d[used]
-        nw = int((d[0, :, 0] != 0).sum())
-        nl = int(os.environ.get("ACX_RING_NL", "1"))
-        ld, cs = d[:, nw - nl:nw, :].reshape(-1, 4), d[:, :nw - nl, :].reshape(-1, 4)
-        print(f"ring debug: {d.shape[0]} workgroups x {nw} waves (s_memtime ticks)")
-        print(f"  loader:   total {ld[:, 0].mean():.0f}  blocked-on-space {ld[:, 1].mean():.0f}  vmcnt-wait {ld[:, 2].mean():.0f}  "
-              f"fills {(ld[:, 3] >> 32).mean():.0f}  blocked-drains {(ld[:, 3] & 0xffffffff).mean():.0f}")
-        print(f"  consumer: total {cs[:, 0].mean():.0f}  wait-for-fill {cs[:, 1].mean():.0f}  wait-for-gather {cs[:, 2].mean():.0f}  slots {cs[:, 3].mean():.0f}")
     assert int(res[0]) == 0 or os.environ.get("ACX_ABLATION"), "witness must verify"
     print(f"r1cs n=2^{log_n} copies={copies}: {us:9.2f} us/launch  {n / us * 1e6:.3e} constraints/s  "
           f"alg {b / 1e6:.2f} MB -> {b / us * 1e-3:.1f} GB/s ({b / us * 1e-3 / 8000 * 100:.1f}% of 8 TB/s)  nnz={nnz} m_ref={m_ref}")

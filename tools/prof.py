@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/prof")
     ap.add_argument("--groups", default="sq,fetch,write")
     ap.add_argument("--match", default="")
+    ap.add_argument("--pass-timeout", type=int, default=240)
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
@@ -42,7 +43,11 @@ def main():
     for name, flags in runs:
         d = os.path.join(a.out, name)
         with open(os.path.join(a.out, name + ".log"), "w") as log:
-            subprocess.call(["rocprofv3"] + flags + ["-d", d, "-o", name, "--"] + cmd, stdout=log, stderr=log, env=env)
+            try:    # some counter groups crash rocprofv3 on this image and then hang: bound every pass
+                subprocess.call(["rocprofv3"] + flags + ["-d", d, "-o", name, "--"] + cmd, stdout=log, stderr=log, env=env,
+                                timeout=a.pass_timeout)
+            except subprocess.TimeoutExpired:
+                print(f"pass {name}: timed out after {a.pass_timeout} s", file=sys.stderr)
     stats, counters = {}, {}
     for db in glob.glob(os.path.join(a.out, "trace", "**", "*.db"), recursive=True):
         cur = sqlite3.connect(db).cursor()
