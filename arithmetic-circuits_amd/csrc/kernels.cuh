@@ -78,7 +78,7 @@ __device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restri
 // lane idles in the multiply loop.  Rows longer than kSellMaxLen in any matrix (the 2^j row of a
 // Split gate, src/QAP.hs:447-459) stay in CSR and are handled by k_r1cs_residual_rows.
 constexpr int kSlice = 64;
-constexpr int kSellMaxLen = 8;
+constexpr int kSellMaxLen = 6;   // = kWideTerms: one deferred reduction per row and matrix, no partial accumulator
 constexpr int kSellWindow = 4096;
 constexpr u32 kNoRow = 0xffffffffu;
 
@@ -168,16 +168,12 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
     // costs one L1 tag lookup per lane), not by VALU or HBM bytes.  So: the gather of slot q is
     // issued first, then the stream loads of slot q+1, and only the gather is waited for (vmcnt
     // retires in order), which keeps a value-stream request in flight during every multiply.
-    bool have = false;
-    int terms = 0;
+    static_assert(kSellMaxLen <= kWideTerms, "a SELL row is reduced once");
+    if (q0 == q1) return acc;
     Wide wide;
-    uint2 t = make_uint2(0, kNoRow);
-    uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-    if (q0 < q1) {
-        t = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
-        lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
-        hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
-    }
+    uint2 t = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
+    uint4 lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
+    uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
     for (u32 q = q0; q < q1; ++q) {
         const uint4* px = w + 2 * (u64)(t.y == kNoRow ? 0u : t.y);   // padding: value 0 * w[0]
         const uint4 xlo = gload(px), xhi = gload(px + 1);
@@ -192,15 +188,9 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
         }
         const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
         const Fe x = fe_unpack(xw);
-        if (terms == 0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
-        if (++terms == kWideTerms || q + 1 == q1) {
-            const Fe part = wide_reduce<F>(wide);
-            acc = have ? fe_add<F>(acc, part) : part;
-            have = true;
-            terms = 0;
-        }
+        if (q == q0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
     }
-    return acc;
+    return wide_reduce<F>(wide);
 }
 
 struct ResidualOut {
@@ -266,13 +256,20 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
     // largest system, so workgroups beyond this system's own range must not run
     if (blockIdx.x >= 8 * per_xcd || tile >= tiles) return;
     const u32 slice = tile * 4 + threadIdx.x / kSlice, lane = threadIdx.x % kSlice;
+    // <A,w> waits in LDS while <B,w> and <C,w> are formed: nine registers less, which is what takes
+    // the kernel from 4 to 5 waves per SIMD (it is bound by memory latency x concurrency)
+    __shared__ u32 park[kLimbs][kBlock];
     Fe a = fe_zero(), b = a, c = a;
     u32 row = kNoRow;
     if (slice < S.n_slices) {
         row = gload(S.perm + slice * kSlice + lane);
         a = sell_dot<F, false>(S.A, S.w, slice, lane);
+#pragma unroll
+        for (int i = 0; i < kLimbs; ++i) park[i][threadIdx.x] = a.l[i];
         b = sell_dot<F, false>(S.B, S.w, slice, lane);
         c = S.unit_c ? sell_dot<F, true>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
+#pragma unroll
+        for (int i = 0; i < kLimbs; ++i) a.l[i] = park[i][threadIdx.x];
     }
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
 }
