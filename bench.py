@@ -189,11 +189,14 @@ def main():
     kernel_us = e0.elapsed_time(e1) * 1e3 / a.steps
     assert int(results[:, 0].abs().sum()) == 0, "a satisfying witness was rejected"     # parity gate of the timed config
 
-    # negative control outside the timed region: one flipped witness limb must be caught
+    # negative control outside the timed region: one flipped witness limb must be caught.  A full
+    # batched launch like the timed ones, so that every k_r1cs_sell call in a profile of this command
+    # is the same workload (the rocprofv3 average in profiles/ is comparable with kernel_us).
     neg = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
     wbad = witnesses[0].clone()
     wbad[77, 0] ^= 1          # flip the lowest bit of limb 0 of one witness entry
-    systems[0].verify_dev(wbad.data_ptr(), neg.data_ptr())
+    neg_batch = acx.Batch(ctx, systems, [wbad.data_ptr()] + [w.data_ptr() for w in witnesses[1:]], neg.data_ptr())
+    neg_batch.verify_dev()
     ctx.sync()
     assert int(neg[0]) > 0, "a corrupted witness was accepted"
 
