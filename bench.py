@@ -43,12 +43,12 @@ def to_dev(ctx, arr):
     return t
 
 
-def cpu_baseline(sample, budget_s=12.0):
+def cpu_baseline(sample, field="bn254", budget_s=12.0):
     """The CPU restatement (oracle/acx_oracle.c, "port") timed on this host's cores on a bounded
     sample of the same workload: one 2^16-constraint system verified `repeat` times per call
     (threads persist across the repeats of a call), calls repeated for ~budget_s seconds."""
     from oracle.c_oracle import COracle
-    orc = COracle("bn254")
+    orc = COracle(field)
     mats, w, n, m = sample
     threads = os.cpu_count() or 1
     repeat = 64
@@ -231,8 +231,8 @@ def main():
             pass
         if world == 1 and not a.no_ntt:
             out["ntt"] = bench_ntt(ctx, stream, a.field)
-        if world == 1 and not a.no_cpu and a.field == "bn254":
-            out["cpu_baseline"] = cpu_baseline(sample)
+        if world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(sample, a.field)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
