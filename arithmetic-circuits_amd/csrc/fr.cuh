@@ -110,25 +110,6 @@ __device__ __forceinline__ void fe_store(uint4* __restrict__ p, const Fe& a) {
     *(g_v4u32_t*)(p + 1) = hi;
 }
 
-// ---- expanded ("limb") storage: 48 bytes per element, no unpacking on load -----------------------
-// Used where an operand is re-read many times from cache (the witness vector of the R1CS kernel):
-// { l0..l3 } { l4..l7 } { l8, 0, 0, 0 } as three uint4.  Values are strictly normalised, < 2p.
-__device__ __forceinline__ Fe fe_load_limbs(const uint4* __restrict__ p) {
-    const uint4 lo = p[0], hi = p[1];
-    const u32 top = reinterpret_cast<const u32*>(p + 2)[0];
-    Fe r;
-    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w;
-    r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
-    r.l[8] = top;
-    return r;
-}
-
-__device__ __forceinline__ void fe_store_limbs(uint4* __restrict__ p, const Fe& a) {
-    p[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
-    p[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
-    p[2] = make_uint4(a.l[8], 0, 0, 0);
-}
-
 // ---- carries --------------------------------------------------------------------------------
 // Sequential carry propagation; limbs may be up to 2^32-1 on entry.
 __device__ __forceinline__ void fe_carry(Fe& a) {
