@@ -363,7 +363,7 @@ def test_hip_ops_distributed_layer_world1(request, acx):
 @pytest.mark.parametrize("field,seed", [("bn254", 1), ("bn254", 2), ("bls12_381", 3)])
 def test_generic_random_csr_vs_oracle(request, acx, field, seed):
     """acx_r1cs_load on arbitrary sparse matrices: empty rows, rows of 1..40 entries (the SELL
-    layout's 6-term reduction chunks, its 8-entry cut-over to the CSR path for long rows), zero
+    layout's single 6-term reduction, its cut-over to the CSR path above 6 entries), zero
     and maximal values, a NON-unit C matrix, n not a multiple of 64 -- residuals, flags, h(x) and
     per-wire polynomials bit-equal to the oracle."""
     ctx, orc = _ctx(request, field), _orc(request, field)
