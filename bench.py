@@ -200,6 +200,20 @@ def main():
     ctx.sync()
     assert int(neg[0]) > 0, "a corrupted witness was accepted"
 
+    # for reference: ONE 2^16-constraint system per launch (configs[1] taken literally; cache resident)
+    single_us = None
+    if rank == 0 and world == 1:
+        with torch.cuda.stream(stream):
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(5):
+                systems[0].verify_dev(witnesses[0].data_ptr(), neg.data_ptr())
+            s0.record(stream)
+            for _ in range(50):
+                systems[0].verify_dev(witnesses[0].data_ptr(), neg.data_ptr())
+            s1.record(stream)
+            s1.synchronize()
+            single_us = s0.elapsed_time(s1) * 1e3 / 50
+
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -216,6 +230,7 @@ def main():
             "config": {"workload": f"r1cs_verify: {a.copies} independent 2^{a.logn}-constraint mulgraph systems per GPU per "
                                    f"step, one batched launch (k=2, n_in=1024, window=4096, seeds 0xAC355+1000*rank+c)",
                        "constraints_per_step_per_gpu": a.copies * n, "nnz_per_step_per_gpu": nnz_total,
+                       "single_system_launch_us": single_us,
                        "field": a.field + "_fr", "parallelism": f"rows sharded x{world}, 1 verdict all-reduce per {ring} steps" if use_dist else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
