@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--field", default="bn254", choices=["bn254", "bls12_381"])
     ap.add_argument("--force-dist", action="store_true",
                     help="run the collective code path even with one rank (RCCL smoke test on a 1-GPU box)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (with ACX_BENCH_ONE_DEVICE=1: every rank on cuda:0) lets the "
+                         "multi-rank control flow be tested on a 1-GPU box")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     a = ap.parse_args()
@@ -110,13 +113,18 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
+    if os.environ.get("ACX_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_dist
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = acx.Context(a.field, local_rank)
     stream = torch.cuda.ExternalStream(ctx.stream)

@@ -653,3 +653,26 @@ def test_r1cs_2_24_rows_block_diagonal_properties(request, acx):
     support = np.nonzero(res.any(axis=1))[0]
     assert set(int(x) for x in support) == expect
     del r
+
+
+# ------------------------------------------------------------------ bench.py multi-rank control flow on one GPU
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device():
+    """The N > 1 path of bench.py (per-rank systems, half-ring verdict all-reduce, MAX-over-ranks timing,
+    one JSON line from rank 0) with two ranks sharing cuda:0 over gloo: RCCL needs one GPU per rank, the
+    control flow does not."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ACX_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20",
+           "--warmup", "3", "--copies", "4", "--no-cpu", "--no-ntt"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["constraints_per_step_per_gpu"] == 4 << 16
+    assert abs(d["value"] - 2 * (4 << 16) * 20 / (d["ms_per_step"] * 20 * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d and "roofline" in d
