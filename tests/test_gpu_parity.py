@@ -676,3 +676,16 @@ def test_bench_two_ranks_on_one_device():
     assert d["config"]["constraints_per_step_per_gpu"] == 4 << 16
     assert abs(d["value"] - 2 * (4 << 16) * 20 / (d["ms_per_step"] * 20 * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and "roofline" in d
+
+
+@pytest.mark.gpu
+def test_sharded_layer_two_ranks_on_one_device():
+    """ShardedR1CS and the four-step DistributedNTT with the HIP local kernels, world size 2, both ranks on
+    cuda:0 over gloo (tests/dist_worker_gpu.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29618", os.path.join(root, "tests", "dist_worker_gpu.py")]
+    out = subprocess.run(cmd, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "dist gpu worker ok 2" in out.stdout
