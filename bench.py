@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with ACX_BENCH_ONE_DEVICE=1: every rank on cuda:0) lets the "
                          "multi-rank control flow be tested on a 1-GPU box")
+    ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed launches before the warmup steps (clock ramp)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     a = ap.parse_args()
@@ -174,6 +175,14 @@ def main():
                 pending[h] = None
 
     with torch.cuda.stream(stream):
+        # Clock ramp: from idle the GPU needs ~250 launches (35 ms) to reach its sustained clock
+        # (tools/microbench/ramp.py: 150 us per step falling to 130).  A fixed untimed pre-run brings it
+        # there whatever --warmup the caller chose; the W warmup steps and the K timed steps follow.
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < a.prewarm:
+            for _ in range(32):
+                batches[0].verify_dev()
+            ctx.sync()
         for i in range(a.warmup):
             step(i)
         drain()
