@@ -175,9 +175,15 @@ def main():
                 pending[h] = None
 
     with torch.cuda.stream(stream):
+        if use_dist:        # first use of the collectives (communicator set-up, kernel load) stays out of the timed region
+            dist.barrier()
+            for _ in range(2):
+                dist.all_reduce(results, op=dist.ReduceOp.SUM, async_op=True).wait()
+            torch.cuda.synchronize()
         # Clock ramp: from idle the GPU needs ~250 launches (35 ms) to reach its sustained clock
-        # (tools/microbench/ramp.py: 150 us per step falling to 130).  A fixed untimed pre-run brings it
-        # there whatever --warmup the caller chose; the W warmup steps and the K timed steps follow.
+        # (tools/microbench/ramp.py: 150 us per step falling to 130), and it falls back within
+        # milliseconds of idling.  A fixed untimed pre-run brings it there whatever --warmup the caller
+        # chose; the W warmup steps, a (by now cheap) barrier and the K timed steps follow immediately.
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < a.prewarm:
             for _ in range(32):
@@ -200,9 +206,11 @@ def main():
             tail.wait()
         drain()
         torch.cuda.synchronize()
+        # the clock stops here: the tail all-reduce above completes only when every rank has contributed,
+        # i.e. finished its K steps, and the MAX over ranks below is the job's time
+        dt = time.perf_counter() - t0
         if use_dist:
             dist.barrier()
-        dt = time.perf_counter() - t0
     kernel_us = e0.elapsed_time(e1) * 1e3 / a.steps
     assert int(results[:, 0].abs().sum()) == 0, "a satisfying witness was rejected"     # parity gate of the timed config
 
