@@ -22,7 +22,19 @@ def alg_bytes(mats, n):
     return 36 * nnz + 12 * (n + 1) + 32 * m_ref + 8, nnz, m_ref
 
 
+PREWARM_S = float(os.environ.get("ACX_KBENCH_PREWARM", "0.25"))
+
+
 def time_stream(stream, fn, reps, warmup=3):
+    """Average launch time in us.  From idle the GPU needs ~35 ms of work to reach its sustained clock
+    (tools/microbench/ramp.py) and measures ~15 % slower until then, so the same call is repeated for
+    PREWARM_S seconds first (ACX_KBENCH_PREWARM=0 gives the from-idle figure older notes quote)."""
+    import time as _time
+    t0 = _time.perf_counter()
+    while _time.perf_counter() - t0 < PREWARM_S:
+        for _ in range(8):
+            fn()
+        stream.synchronize()
     for _ in range(warmup):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
