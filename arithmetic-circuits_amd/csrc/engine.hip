@@ -89,6 +89,7 @@ struct acx_r1cs {
     uint64_t plan_n_in = 0;
     u32 *ev_items = nullptr, *ev_row = nullptr, *ev_wire_ofs = nullptr, *ev_wires = nullptr;
     uint8_t* ev_kind = nullptr;
+    uint4* ev_mul = nullptr;             // per plan item: the Mul gate's record (k_eval_level)
     bool has_csc = false;
     uint4* d_w = nullptr;  // witness staging, m elements
 };
@@ -563,6 +564,7 @@ void free_r1cs_device(acx_r1cs* r) {
     }
     if (r->perm) (void)hipFree(r->perm);
     if (r->long_rows) (void)hipFree(r->long_rows);
+    if (r->ev_mul) { (void)hipFree(r->ev_mul); r->ev_mul = nullptr; }
     if (r->ev_items) (void)hipFree(r->ev_items);
     if (r->ev_row) (void)hipFree(r->ev_row);
     if (r->ev_wire_ofs) (void)hipFree(r->ev_wire_ofs);
@@ -884,12 +886,27 @@ int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots,
         }
         wofs[ng] = (uint32_t)hc.wire_ofs[ng];
         for (size_t i = 0; i < hc.wires.size(); ++i) wflat[i] = (uint32_t)hc.flat(hc.wires[i]);
+        // level-ordered records of the Mul gates (entry ranges of their A and B rows in the device CSR)
+        std::vector<uint32_t> ptr_a(hc.n_rows() + 1), ptr_b(hc.n_rows() + 1);
+        HIP_TRY(hipMemcpy(ptr_a.data(), r->M[0].ptr, ptr_a.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ptr_b.data(), r->M[1].ptr, ptr_b.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> mul(plan.items.size() * 4, 0xffffffffu);
+        for (size_t t = 0; t < plan.items.size(); ++t) {
+            const uint32_t g = plan.items[t];
+            if (hc.kind[g] != ACX_GATE_MUL) continue;
+            const uint32_t ri = row[g], na = ptr_a[ri + 1] - ptr_a[ri], nb = ptr_b[ri + 1] - ptr_b[ri];
+            if (na > 0xffffu || nb > 0xfffeu) continue;          // generic path
+            mul[4 * t] = wflat[hc.wire_ofs[g]];
+            mul[4 * t + 1] = ptr_a[ri];
+            mul[4 * t + 2] = ptr_b[ri];
+            mul[4 * t + 3] = na | (nb << 16);
+        }
         auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
             return hipMalloc(dst, bytes ? bytes : 4) == hipSuccess && (bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
         };
         if (up((void**)&r->ev_items, plan.items.data(), plan.items.size() * 4) && up((void**)&r->ev_row, row.data(), row.size() * 4) &&
             up((void**)&r->ev_wire_ofs, wofs.data(), wofs.size() * 4) && up((void**)&r->ev_wires, wflat.data(), wflat.size() * 4) &&
-            up((void**)&r->ev_kind, hc.kind.data(), hc.kind.size())) {
+            up((void**)&r->ev_kind, hc.kind.data(), hc.kind.size()) && up((void**)&r->ev_mul, mul.data(), mul.size() * 4)) {
             r->has_plan = true;
             r->plan_level_ofs = plan.level_ofs;
             r->plan_written = plan.written;
@@ -984,12 +1001,14 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) as[1 + i] = 1;
     for (uint32_t k : r->plan_eq_split_inputs)
         if (!as[k]) return fail(ACX_ERR_UNDEFINED_WIRE, "evalGate: the impossible happened (Equal/Split input unassigned)");
-    // initial witness: constant 1, the given inputs, everything else 0
-    std::vector<acx_fr> w0(r->m);
+    // initial witness: constant 1, the given inputs, everything else 0 -- zeroed on the device (the
+    // all-zero word is 0 in dev format too); only the head travels over PCIe
+    std::vector<acx_fr> w0(1 + n_use);
     std::memset(w0.data(), 0, w0.size() * 32);
     w0[0].b[0] = 1;
     for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) w0[1 + i] = inputs[i];
-    ACX_TRY(upload_elements(c, w0.data(), r->m, r->d_w));
+    HIP_TRY(hipMemsetAsync(r->d_w, 0, r->m * 32, c->stream));
+    ACX_TRY(upload_elements(c, w0.data(), w0.size(), r->d_w));
     Exp256 pm2;
     {
         H256 ex = hf.modulus();
@@ -1001,7 +1020,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     for (size_t l = 0; l < n_levels; ++l) {
         const uint32_t lo = r->plan_level_ofs[l], cnt = r->plan_level_ofs[l + 1] - lo;
         if (cnt == 0) continue;
-        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires};
+        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo};
         DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level<F>), dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
                                              G, A, B, r->d_w, pm2));
     }

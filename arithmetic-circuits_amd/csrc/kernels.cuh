@@ -42,8 +42,7 @@ __global__ __launch_bounds__(kBlock) void k_convert(const uint4* __restrict__ in
 // matrix of every gate the reference emits, src/QAP.hs:371-474): the dot is a plain sum of
 // witness entries and the value stream is never read.
 template <class F, bool UNIT>
-__device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restrict__ w, u64 row) {
-    const u32 e0 = M.rowptr[row], e1 = M.rowptr[row + 1];
+__device__ __forceinline__ Fe csr_range_dot(const CsrDev& M, const uint4* __restrict__ w, u32 e0, u32 e1) {
     Fe acc = fe_zero();
     if (UNIT) {
         for (u32 e = e0; e < e1; ++e) {
@@ -65,6 +64,10 @@ __device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restri
         acc = (base == e0) ? part : fe_add<F>(acc, part);
     }
     return acc;
+}
+template <class F, bool UNIT>
+__device__ __forceinline__ Fe csr_row_dot(const CsrDev& M, const uint4* __restrict__ w, u64 row) {
+    return csr_range_dot<F, UNIT>(M, w, M.rowptr[row], M.rowptr[row + 1]);
 }
 
 // ---- SELL-64 device layout of a constraint matrix -------------------------------------------------
@@ -618,6 +621,7 @@ struct EvalGates {
     const u32* row;          // per gate: constraint row of a Mul gate in the stored row order
     const u32* wire_ofs;     // per gate: offset into wires (n_gates + 1)
     const u32* wires;        // flat wire indices: Mul {out}, Equal {i, m, out}, Split {inp, outs...}
+    const uint4* mul;        // per item, level order: Mul gate {out wire, first A entry, first B entry, nA | nB << 16}, else .w = ~0
 };
 
 template <class F>
@@ -625,6 +629,16 @@ __global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, Cs
                                                       Exp256 pm2) {
     const u32 t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= G.count) return;
+    // Mul gates (nearly all of a circuit) carry everything in ONE level-ordered record: a level is a
+    // chain of dependent loads -- item -> gate -> row -> row pointers -> entries -> witness -- and costs
+    // its latency, not its bandwidth, so the record cuts the chain to record -> entries -> witness
+    const uint4 it = gload(G.mul + t);
+    if (it.w != 0xffffffffu) {
+        const Fe a = csr_range_dot<F, false>(A, w, it.y, it.y + (it.w & 0xffffu));
+        const Fe b = csr_range_dot<F, false>(B, w, it.z, it.z + (it.w >> 16));
+        fe_store(w + 2 * (u64)it.x, fe_mul<F>(a, b));
+        return;
+    }
     const u32 g = G.items[t];
     const u32* gw = G.wires + G.wire_ofs[g];
     const u32 kd = G.kind[g];
