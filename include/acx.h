@@ -151,7 +151,11 @@ int acx_circuit_rows(const acx_circuit* c, const acx_fr* roots, uint64_t n_roots
                      uint32_t* rowptr, uint32_t* col, acx_fr* val);
 
 /* ---------------------------------------------------------------- R1CS / GenQAP (device) */
-/* Pre-flattened constraint system (a GenQAP in row form): n rows, m wires. */
+/* Pre-flattened constraint system (a GenQAP in row form): n rows, m wires.  Rows need not be sorted by
+ * column; duplicate columns in a row are summed.  Limits: 1 <= m < 2^32 - 1, n < 2^32 - 1, n <= 2^two-adicity
+ * of the field (2^28 for BN254 Fr, 2^32 for BLS12-381 Fr), fewer than 2^32 entries per matrix
+ * (ACX_ERR_TOO_LARGE otherwise); columns must be < m and values canonical (ACX_ERR_INVALID_ARG /
+ * ACX_ERR_NONCANONICAL). */
 int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B,
                   const acx_csr* C, acx_r1cs** out);
 void acx_r1cs_destroy(acx_r1cs* r);
