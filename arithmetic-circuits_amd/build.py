@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacx.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["fr.cuh", "kernels.cuh", "field_consts.h", "host_field.h", "circuit_host.h",
+HEADERS = ["fr.hip.h", "kernels.hip.h", "ntt_r4.hip.h", "field_consts.h", "host_field.h", "circuit_host.h",
            os.path.join("..", "..", "include", "acx.h")]
 
 

@@ -9,12 +9,14 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/acx.h"
 #include "circuit_host.h"
 #include "host_field.h"
-#include "kernels.cuh"
+#include "kernels.hip.h"
+#include "ntt_r4.hip.h"
 
 using namespace acx;
 
@@ -41,6 +43,15 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 // ------------------------------------------------------------------------------------ handles
+struct NttCfg {
+    int impl = 1;            // 0 tile, 1 r4
+    int xchg = 0;            // 0 LDS, 1 DPP / permlane
+    uint32_t tile_log = 12;
+    uint32_t direct_tw = 20;
+    int n_digits = 0;
+    uint32_t digits[4] = {0, 0, 0, 0};
+};
+
 struct acx_ctx {
     int field = 0;
     int device = 0;
@@ -49,6 +60,8 @@ struct acx_ctx {
     std::mutex mu;
     std::map<std::pair<uint32_t, int>, uint4*> twiddles;  // (log_m, inverse) -> omega_M^j, j < M
     std::map<std::pair<uint32_t, int>, uint4*> tw_low;    // (log_n, inverse) -> omega_N^j, j < 1024
+    std::map<std::tuple<uint32_t, uint64_t, int, uint32_t>, uint4*> tw_scaled;   // (log_m, count, inverse, log_n of folded 1/N)
+    NttCfg ntt;
     uint4* ntt_scratch = nullptr;                          // ping-pong buffer of the multi-pass NTT
     size_t ntt_scratch_bytes = 0;
     uint4* coset_lo = nullptr;                             // g^j (j < 1024), g^(1024 j): last shift used
@@ -74,7 +87,7 @@ struct acx_r1cs {
     DevMatrix M[3];
     DevMatrix T[3];        // CSC, built lazily for acx_qap_columns
     bool unit_c = false;   // every stored C value is 1: the kernel never reads C's value stream
-    // SELL-64 layout used by the residual kernel (kernels.cuh)
+    // SELL-64 layout used by the residual kernel (kernels.hip.h)
     u32* sell_ofs[3] = {nullptr, nullptr, nullptr};
     uint2* sell_tail[3] = {nullptr, nullptr, nullptr};
     uint4* sell_val[3] = {nullptr, nullptr, nullptr};
@@ -148,10 +161,10 @@ inline uint32_t ceil_log2(uint64_t n) {
 }
 
 // ---- field dispatch ---------------------------------------------------------------------
-#define DISPATCH_FIELD(ctx, CALL)                         \
+#define DISPATCH_FIELD(ctx, ...)                          \
     do {                                                  \
-        if ((ctx)->field == ACX_FIELD_BN254_FR) { using F = Bn254Fr; CALL; }        \
-        else { using F = Bls12381Fr; CALL; }              \
+        if ((ctx)->field == ACX_FIELD_BN254_FR) { using F = Bn254Fr; __VA_ARGS__; }        \
+        else { using F = Bls12381Fr; __VA_ARGS__; }       \
     } while (0)
 
 int launch_convert(acx_ctx* c, bool to_dev, const void* in, void* out, uint64_t count, uint32_t* d_err) {
@@ -223,6 +236,26 @@ int get_low_table(acx_ctx* c, uint32_t log_n, int inverse, uint4** out) {
     return ACX_OK;
 }
 
+// first * omega_M^j for j < count (M = 2^log_m; omega^-1 when inverse); first = 1 or 1/2^scaled_log_n.  Cached.
+int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, uint32_t scaled_log_n, uint4** out) {
+    if (scaled_log_n == 0 && count == (1ull << log_m)) return get_pow_table(c, log_m, inverse, out);
+    if (scaled_log_n == 0 && count == 1024) return get_low_table(c, log_m, inverse, out);
+    const auto key = std::make_tuple(log_m, count, inverse, scaled_log_n);
+    auto it = c->tw_scaled.find(key);
+    if (it != c->tw_scaled.end()) { *out = it->second; return ACX_OK; }
+    uint4* tw = nullptr;
+    HIP_TRY(hipMalloc((void**)&tw, count * 32));
+    H256 w = c->hf.root_of_unity((int)log_m);
+    if (inverse) w = c->hf.inv(w);
+    const H256 first = c->hf.inv(c->hf.from_u64(1ull << scaled_log_n));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, tw,
+                                         count, dev_arg(c->hf, w), dev_arg(c->hf, first)));
+    HIP_TRY(hipGetLastError());
+    c->tw_scaled[key] = tw;
+    *out = tw;
+    return ACX_OK;
+}
+
 // g^j (j < 1024) and g^(1024 j) (j < N/1024) for the coset factor; the last (g, log_n) is kept.
 int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, uint4** lo, uint4** hi) {
     const uint64_t hi_count = log_n > 10 ? (1ull << (log_n - 10)) : 0;
@@ -252,22 +285,88 @@ int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, uint4** 
 inline uint64_t pow2_floor(uint64_t x) { uint64_t p = 1; while (p * 2 <= x) p *= 2; return p; }
 inline uint32_t ilog2(uint64_t x) { uint32_t k = 0; while ((1ull << (k + 1)) <= x) ++k; return k; }
 
-// In-place batched NTT on dev-format data (multi-pass tiled kernel, kernels.cuh).  Caller holds ctx->mu.
+// ---- NTT planning ---------------------------------------------------------------------------------
+// A length-2^log_n transform is factored into P digits; pass p transforms digit p (tile kernel) and
+// multiplies by the inter-pass twiddle.  Two kernel families: k_ntt_tile (<= 8 bits per pass, one
+// radix-2 stage per LDS round trip; every size) and k_ntt_r4 (<= 12 bits per pass, four elements
+// per lane in registers; log_n >= 10).  Tunables (development / A-B measurements), read once per
+// context: ACX_NTT_IMPL=tile|r4, ACX_NTT_XCHG=lds|dpp, ACX_NTT_TILE_LOG (max log2 elements per r4
+// tile, default 12), ACX_NTT_DIRECT_TW (largest log2 size of a direct inter-pass twiddle table,
+// default 20), ACX_NTT_DIGITS="10,10" (forces the digit split of every transform of that size).
+NttCfg ntt_cfg_from_env() {
+    NttCfg g;
+    if (const char* e = std::getenv("ACX_NTT_IMPL")) g.impl = std::string(e) == "tile" ? 0 : 1;
+    if (const char* e = std::getenv("ACX_NTT_XCHG")) g.xchg = std::string(e) == "dpp" ? 1 : 0;
+    if (const char* e = std::getenv("ACX_NTT_TILE_LOG")) g.tile_log = (uint32_t)std::max(6, std::min(12, std::atoi(e)));
+    if (const char* e = std::getenv("ACX_NTT_DIRECT_TW")) g.direct_tw = (uint32_t)std::max(0, std::min(24, std::atoi(e)));
+    if (const char* e = std::getenv("ACX_NTT_DIGITS")) {
+        for (const char* q = e; *q && g.n_digits < 4;) {
+            g.digits[g.n_digits++] = (uint32_t)std::strtoul(q, const_cast<char**>(&q), 10);
+            if (*q == ',') ++q;
+        }
+    }
+    return g;
+}
+
+// (LP, LG) instances of k_ntt_r4 that are compiled
+template <class F, int XCHG>
+bool launch_r4(int lp, int lg, unsigned tiles, hipStream_t st, const NttPass& Q) {
+#define ACX_R4_CASE(LP_, LG_)                                                                                    \
+    if (lp == LP_ && lg == LG_) {                                                                               \
+        hipLaunchKernelGGL((k_ntt_r4<F, LP_, LG_, XCHG>), dim3(tiles), dim3(1u << (LP_ - 2 + LG_)), 0, st, Q);   \
+        return true;                                                                                            \
+    }
+    ACX_R4_CASE(6, 0) ACX_R4_CASE(6, 2) ACX_R4_CASE(6, 4)
+    ACX_R4_CASE(8, 0) ACX_R4_CASE(8, 2)
+    ACX_R4_CASE(10, 0) ACX_R4_CASE(10, 1) ACX_R4_CASE(10, 2)
+    ACX_R4_CASE(12, 0)
+#undef ACX_R4_CASE
+    return false;
+}
+inline int r4_pick_lg(int lp, int want) {      // largest compiled LG <= want, or -1
+    static const int kLg[4][3] = {{0, 2, 4}, {0, 2, -1}, {0, 1, 2}, {0, -1, -1}};
+    const int* row = kLg[(lp - 6) / 2];
+    int best = -1;
+    for (int i = 0; i < 3; ++i) if (row[i] >= 0 && row[i] <= want) best = std::max(best, row[i]);
+    return best;
+}
+
+// In-place batched NTT on dev-format data.  Caller holds ctx->mu.
 //   forward: X[k] = sum_i x[i] (shift * omega^k)^i      inverse: undoes it.
 int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inverse, const H256* shift_mont) {
     if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
     if (batch == 0) return ACX_OK;
     const HostField& hf = c->hf;
+    const NttCfg& cfg = c->ntt;
     const uint64_t N = 1ull << log_n;
-    // factor N into P digits of at most 8 bits
-    const int P = log_n <= 8 ? 1 : (int)((log_n + 7) / 8);
+    const uint64_t batch_pow2 = batch & (~batch + 1);   // largest power of two dividing batch
+    // ---- digits
+    bool r4 = cfg.impl == 1 && log_n >= 10 && log_n <= 36;
+    int P = 0;
     uint32_t lg[4] = {0, 0, 0, 0};
-    for (int p = 0; p < P; ++p) lg[p] = log_n / P + ((uint32_t)p < log_n % P ? 1 : 0);
+    if (r4) {
+        uint32_t sum = 0;
+        for (int i = 0; i < cfg.n_digits; ++i) sum += cfg.digits[i];
+        if (cfg.n_digits && sum == log_n) {
+            P = cfg.n_digits;
+            for (int i = 0; i < P; ++i) lg[i] = cfg.digits[i];
+        } else if (log_n <= 12 && (log_n % 2 == 0 || batch_pow2 >= 2)) {
+            P = 1; lg[0] = log_n;
+        } else {
+            P = log_n <= 24 ? 2 : 3;
+            for (int p = 0; p < P; ++p) lg[p] = log_n / P + ((uint32_t)p < log_n % P ? 1 : 0);
+        }
+        for (int p = 0; p < P; ++p) if (lg[p] < 5 || lg[p] > 12) r4 = false;
+    }
+    if (!r4) {
+        P = log_n <= 8 ? 1 : (int)((log_n + 7) / 8);
+        for (int p = 0; p < P; ++p) lg[p] = log_n / P + ((uint32_t)p < log_n % P ? 1 : 0);
+    }
     uint64_t Wt[4], Vt[4];   // input / output weight of each digit
     for (int p = 0; p < P; ++p) {
         Wt[p] = 1; Vt[p] = 1;
-        for (int r = p + 1; r < P; ++r) Wt[p] <<= lg[r];
-        for (int r = 0; r < p; ++r) Vt[p] <<= lg[r];
+        for (int q = p + 1; q < P; ++q) Wt[p] <<= lg[q];
+        for (int q = 0; q < p; ++q) Vt[p] <<= lg[q];
     }
     uint4* scratch = nullptr;
     if (P > 1) {
@@ -286,6 +385,9 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         const H256 base = inverse ? hf.inv(*shift_mont) : *shift_mont;
         ACX_TRY(get_coset_tables(c, base, log_n, &sc_lo, &sc_hi));
     }
+    // the r4 kernel can finish with a plain reduction: 1/N of an inverse transform is folded into the last
+    // inter-pass twiddle table
+    const bool fold_scale = r4 && inverse && !shift_mont && P >= 2;
     for (int p = 0; p < P; ++p) {
         NttPass Q;
         std::memset(&Q, 0, sizeof(Q));
@@ -297,21 +399,35 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         Q.idx_mask = N - 1;
         Q.sc_lo = sc_lo; Q.sc_hi = sc_hi;
         const uint64_t S = 1ull << lg[p];
+        // columns a tile may take (powers of two), and the tile's element budget
+        const uint64_t col_avail = P == 1 ? batch_pow2 : (!last ? (1ull << lg[P - 1]) : (1ull << lg[0]));
+        uint64_t T;
+        int lp = 0, lgrp = 0;
+        if (r4) {
+            const uint32_t odd = lg[p] & 1u;
+            lp = (int)(lg[p] + odd);
+            const uint64_t cap = std::max<uint64_t>(1ull << cfg.tile_log, S << odd);
+            uint64_t t_want = std::min<uint64_t>(cap / S, col_avail);
+            if (t_want < (1ull << odd)) return fail(ACX_ERR_UNSUPPORTED, "NTT plan: odd digit needs two columns");
+            lgrp = r4_pick_lg(lp, (int)ilog2(t_want) - (int)odd);
+            if (lgrp < 0) return fail(ACX_ERR_UNSUPPORTED, "NTT plan: no kernel instance");
+            T = 1ull << (lgrp + odd);
+        } else {
+            T = std::min<uint64_t>(kTileElems / S, col_avail);
+        }
         uint32_t no = 0;
         auto add_outer = [&](uint64_t count, uint64_t sin, uint64_t sout, uint64_t kw, uint64_t iw) {
             if (count <= 1) return;
-            Q.outer[no++] = NttOuter{(u32)count, 0, sin, sout, kw, iw};
+            if (no < (uint32_t)kMaxOuter) Q.outer[no] = NttOuter{(u32)count, 0, sin, sout, kw, iw};
+            ++no;
         };
-        uint64_t T;
         if (P == 1) {
             // columns = independent transforms of the batch
-            T = std::min<uint64_t>(kTileElems / S, batch & (~batch + 1));   // largest power of two dividing batch
             Q.stride_t_in = Q.stride_t_out = 1;
             Q.stride_c_in = Q.stride_c_out = N;
             add_outer(batch / T, T * N, T * N, 0, 0);
         } else if (!last) {
             const uint64_t NP = 1ull << lg[P - 1];
-            T = std::min<uint64_t>(kTileElems / S, NP);
             Q.stride_t_in = Q.stride_t_out = Wt[p];
             Q.stride_c_in = Q.stride_c_out = 1;
             Q.t_kw = Vt[p];
@@ -325,20 +441,20 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
             add_outer(batch, N, N, 0, 0);
             // twiddle w_N^(I*K), I = i_{p+1} W_{p+1}, K = k_1 + ... + k_p V_p
             uint32_t log_m = 0;
-            for (int r = 0; r <= p + 1; ++r) log_m += lg[r];
-            if (log_m <= 16) {
+            for (int q = 0; q <= p + 1; ++q) log_m += lg[q];
+            const uint32_t fold = (fold_scale && next_is_last) ? log_n : 0;
+            if (log_m <= (r4 ? std::max<uint32_t>(cfg.direct_tw, 16) : 16)) {
                 uint4* tw = nullptr;
-                ACX_TRY(get_pow_table(c, log_m, inverse, &tw));
+                ACX_TRY(get_scaled_table(c, log_m, 1ull << log_m, inverse, fold, &tw));
                 Q.tw_mode = 1; Q.tw_lo = tw; Q.tw_shift = ilog2(Wt[p + 1]);
             } else {
                 uint4 *lo = nullptr, *hi = nullptr;
-                ACX_TRY(get_low_table(c, log_n, inverse, &lo));
+                ACX_TRY(get_scaled_table(c, log_n, 1024, inverse, fold, &lo));
                 ACX_TRY(get_pow_table(c, log_n - 10, inverse, &hi));
                 Q.tw_mode = 2; Q.tw_lo = lo; Q.tw_hi = hi; Q.tw_mask = N - 1;
             }
         } else {
             const uint64_t N1 = 1ull << lg[0];
-            T = std::min<uint64_t>(kTileElems / S, N1);
             Q.stride_t_in = 1;            Q.stride_t_out = Vt[p];
             Q.stride_c_in = Wt[0];        Q.stride_c_out = 1;
             add_outer(N1 / T, T * Wt[0], T, 0, 0);
@@ -354,9 +470,20 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
             const H256 s = inverse ? hf.inv(hf.from_u64(N)) : hf.one();
             Q.scale = dev_arg(hf, s);
             Q.scale_mode = (inverse && shift_mont) ? 2 : 1;
+            if (r4 && Q.scale_mode == 1 && (!inverse || fold_scale)) Q.scale_mode = 0;   // nothing left to multiply by
         }
         const uint64_t tiles = batch * N / (S * T);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_tile<F>), dim3((unsigned)tiles), dim3(kBlock), 0, c->stream, Q));
+        if (tiles > 0x7fffffffull) return fail(ACX_ERR_TOO_LARGE, "NTT grid too large");
+        if (r4) {
+            bool ok = false;
+            DISPATCH_FIELD(c, {
+                ok = cfg.xchg == 1 ? launch_r4<F, kXchgDpp>(lp, lgrp, (unsigned)tiles, c->stream, Q)
+                                   : launch_r4<F, kXchgLds>(lp, lgrp, (unsigned)tiles, c->stream, Q);
+            });
+            if (!ok) return fail(ACX_ERR_UNSUPPORTED, "NTT plan: kernel instance missing");
+        } else {
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_tile<F>), dim3((unsigned)tiles), dim3(kBlock), 0, c->stream, Q));
+        }
     }
     HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -687,6 +814,7 @@ int acx_ctx_create(int field, int device_id, acx_ctx** out) {
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->hf = field == ACX_FIELD_BN254_FR ? HostField::make<Bn254Fr>() : HostField::make<Bls12381Fr>();
+    c->ntt = ntt_cfg_from_env();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->d_result, 16) != hipSuccess || hipMalloc((void**)&c->d_err, 4) != hipSuccess) {
         acx_ctx_destroy(c);
@@ -702,6 +830,7 @@ void acx_ctx_destroy(acx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto& kv : c->tw_low) (void)hipFree(kv.second);
+    for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
     if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
     if (c->coset_lo) (void)hipFree(c->coset_lo);
     if (c->coset_hi) (void)hipFree(c->coset_hi);
@@ -724,8 +853,10 @@ int acx_ctx_set_root(acx_ctx* c, uint32_t two_adicity, const acx_fr* omega) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto& kv : c->tw_low) (void)hipFree(kv.second);
+    for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
     c->twiddles.clear();
     c->tw_low.clear();
+    c->tw_scaled.clear();
     c->hf.set_omega_max(w, (int)two_adicity);
     return ACX_OK;
 }

@@ -1,4 +1,4 @@
-// fr.cuh -- 256-bit prime-field arithmetic for gfx950 (CDNA4) device code.
+// fr.hip.h -- 256-bit prime-field arithmetic for gfx950 (CDNA4) device code.
 //
 // Replaces the arithmetic of galois-field-1.0.2 `Prime p` (third party; call sites
 // /root/reference/src/QAP.hs:52,87-90,450 and src/Circuit/Arithmetic.hs:131,143) on the device.

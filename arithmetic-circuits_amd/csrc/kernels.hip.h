@@ -1,7 +1,7 @@
-// kernels.cuh -- gfx950 kernels of the R1CS / QAP hot path.  All new code: the reference
+// kernels.hip.h -- gfx950 kernels of the R1CS / QAP hot path.  All new code: the reference
 // (pure Haskell) has no kernels; each kernel names the reference computation it performs.
 #pragma once
-#include "fr.cuh"
+#include "fr.hip.h"
 
 namespace acx {
 
@@ -305,6 +305,14 @@ __global__ __launch_bounds__(kBlock) void k_pow_table(uint4* __restrict__ tw, u6
     const Fe base = fe_from_arg(base_arg);
     for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < count; j += (u64)gridDim.x * kBlock)
         fe_store(tw + 2 * j, fe_pow<F>(base, j));
+}
+
+// tw[j] = first * base^j for j < count (inter-pass twiddles with the 1/N of an inverse transform folded in)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_pow_table_scaled(uint4* __restrict__ tw, u64 count, FeArg base_arg, FeArg first_arg) {
+    const Fe base = fe_from_arg(base_arg), first = fe_from_arg(first_arg);
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < count; j += (u64)gridDim.x * kBlock)
+        fe_store(tw + 2 * j, fe_mul<F>(fe_pow<F>(base, j), first));
 }
 
 // ---- K3/K4: tiled multi-pass NTT ---------------------------------------------------------------

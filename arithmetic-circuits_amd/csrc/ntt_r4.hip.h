@@ -1,0 +1,250 @@
+// ntt_r4.hip.h -- register-resident NTT pass for gfx950: four elements per lane, two radix-2 DIT
+// stages per round in registers, digit exchanges between rounds.
+//
+// Replaces galois-fft `FFT.fft` / `FFT.interpolate` (third party; call sites
+// /root/reference/src/QAP.hs:521-524) for the large transforms; k_ntt_tile (kernels.hip.h) keeps
+// the small ones.  Same pass descriptor (NttPass) and the same mathematics per pass -- bit-reversed
+// placement, log2(S) radix-2 DIT stages with lazy add/sub, one closing multiplication -- but:
+//
+//   * a thread group of U = 2^(LP-2) lanes owns one column (S = 2^LP points; two columns of
+//     2^(LP-1) points when the pass digit is odd: the spare top "position" bit is the column bit
+//     and its stage is skipped).  Lane u keeps FOUR elements x[0..3] in VGPRs (36 registers).
+//   * Round r works on extended-position bits (2r+1, 2r), which sit in the slot index: stage A
+//     pairs slots (0,1),(2,3), stage B pairs (0,2),(1,3) -- both without leaving the registers.
+//     S = 1024: 5 rounds = 4 exchanges instead of 10 LDS round trips with 10 workgroup barriers.
+//   * Between rounds the slot digit is swapped with a two-bit field of the lane index.  Lane
+//     order is chosen (logical index v = bitrev(u)) so that the FIRST exchange is the one that
+//     crosses wavefronts (LDS + s_barrier) and every later one stays inside a wavefront: those
+//     go through a wave-private LDS window with no barrier at all (DS operations of one wave
+//     execute in order) -- or, with ACX_NTT_XCHG=dpp, through v_permlane32_swap /
+//     v_permlane16_swap / DPP row rotations without touching LDS ("wavefront-shuffle
+//     butterflies").  With v = bitrev(u) a contiguous input row is also read in lane order.
+//   * XOR-swizzled LDS addresses make both sides of every exchange bank-conflict free.
+#pragma once
+#include "kernels.hip.h"
+
+namespace acx {
+
+__device__ __forceinline__ u32 rev2(u32 x) { return ((x & 1u) << 1) | (x >> 1); }
+
+// loose (limbs < 2^29 + 8 after a carry pass, value < 64p) -> strictly normalised, < 2p, without a
+// Montgomery multiplication: ripple the carries, estimate q = floor(top / (P[8] + 1)) <= x / p
+// (q < 64), subtract q * p limb-wise (signed 64-bit column arithmetic), then one conditional
+// subtraction of 2p covers the estimate's slack (remainder < 2p + p/2^20).
+template <class F>
+__device__ __forceinline__ Fe fe_reduce_loose(Fe a) {
+    fe_carry(a);
+    const u32 q = (u32)(((u64)a.l[kLimbs - 1] * (u64)((1ull << 32) / (F::P[kLimbs - 1] + 1))) >> 32);
+    Fe r;
+    long long c = 0;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        const long long t = (long long)a.l[k] - (long long)((u64)q * F::P[k]) + c;
+        r.l[k] = (k < kLimbs - 1) ? ((u32)t & kLimbMask) : (u32)t;
+        c = t >> kLimbBits;
+    }
+    // r in [0, 3p) here (q may be one short of the exact quotient): bring it below 2p
+    return fe_cond_sub<F::P2>(r);
+}
+
+enum NttXchg { kXchgLds = 0, kXchgDpp = 1 };
+
+// ---- intra-wave exchange without LDS ---------------------------------------------------------------
+// Swap registers between lanes that differ in ONE lane bit: lanes with the bit clear give `hi` and
+// receive the partner's `lo`; lanes with the bit set give `lo` and receive the partner's `hi`.
+// (After it, `lo` of a clear lane and `hi`... are unchanged; see xchg_dpp.)
+template <int BIT>
+__device__ __forceinline__ void lane_swap(u32& lo, u32& hi) {
+    if constexpr (BIT == 5) {
+        // v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
+    } else if constexpr (BIT == 4) {
+        // v_permlane16_swap vdst, src: odd rows of vdst <-> even rows of src
+        const auto r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
+    } else {
+        // DPP inside a row of 16 lanes.  send = what this lane gives away, got = partner's gift.
+        const bool set = (threadIdx.x >> BIT) & 1u;
+        const u32 send = set ? lo : hi;
+        u32 got;
+        if constexpr (BIT == 0) got = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+        else if constexpr (BIT == 1) got = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+        else if constexpr (BIT == 3) got = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xF, 0xF, true); // row_ror:8
+        else {                                                                                                     // BIT == 2: lane ^ 4
+            const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x124, 0xF, 0xF, true);   // row_ror:4  -> from lane - 4
+            const u32 dn = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x12C, 0xF, 0xF, true);   // row_ror:12 -> from lane + 4
+            got = set ? up : dn;
+        }
+        if (set) lo = got; else hi = got;
+    }
+}
+
+// ---- the pass kernel ---------------------------------------------------------------------------------
+// LP: even number of extended position bits of a thread group (sub-transform digit rounded up to
+// even); LG: log2(thread groups per workgroup).  blockDim.x = 2^(LP-2+LG), tile = 2^(LP+LG) elements.
+template <class F, int LP, int LG, int XCHG>
+__global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
+    constexpr int LU = LP - 2;
+    constexpr u32 U = 1u << LU;
+    constexpr int R = LP / 2;
+    constexpr u32 ELEMS = 4u << (LU + LG);
+    // an exchange needs LDS when it crosses wavefronts, or always in the LDS flavour
+    constexpr bool kUsesLds = (XCHG == kXchgLds && R > 1) || (LU > 6);
+    __shared__ u32 lds[kUsesLds ? kLimbs : 1][kUsesLds ? ELEMS : 1];
+
+    const u32 ls = P.log_s;                  // LP == ls (even digit) or ls + 1 (odd digit: two columns per group)
+    const u32 odd = (u32)LP - ls;
+    const u32 S = 1u << ls;
+    const u32 t = threadIdx.x, g = t >> LU, u = t & (U - 1);
+    const u32 v = __brev(u) >> (32 - LU);    // logical lane index: holds the already-processed position bits
+    const u32 gbase = g * (4u * U);
+
+    u64 base_in = 0, base_out = 0, K0 = 0, I0 = 0;
+    {
+        u64 tt = blockIdx.x;
+        for (u32 d = 0; d < P.n_outer; ++d) {
+            const u64 idx = tt % P.outer[d].count;
+            tt /= P.outer[d].count;
+            base_in += idx * P.outer[d].stride_in;
+            base_out += idx * P.outer[d].stride_out;
+            K0 += idx * P.outer[d].k_w;
+            I0 += idx * P.outer[d].i_w;
+        }
+    }
+
+    // ---- load: slot e of lane u = input point d = (rev2(e) << (ls-2)) | (u >> odd) of column 2g+(u&odd) | g
+    Fe x[4];
+    {
+        const u32 col = (g << odd) | (u & odd);
+        const u64 cbase = base_in + (u64)col * P.stride_c_in;
+        uint4 raw[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 d = (rev2(e) << (ls - 2)) | (u >> odd);
+            const uint4* p = P.src + 2 * (cbase + (u64)d * P.stride_t_in);
+            raw[2 * e] = gload(p);
+            raw[2 * e + 1] = gload(p + 1);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 w[8] = {raw[2 * e].x, raw[2 * e].y, raw[2 * e].z, raw[2 * e].w,
+                              raw[2 * e + 1].x, raw[2 * e + 1].y, raw[2 * e + 1].z, raw[2 * e + 1].w};
+            x[e] = fe_unpack(w);
+            if (P.scale_on_load) {
+                const u32 d = (rev2(e) << (ls - 2)) | (u >> odd);
+                const u64 off = cbase + (u64)d * P.stride_t_in;
+                x[e] = fe_mul<F>(x[e], two_level_pow<F>(P.sc_lo, P.sc_hi, off & P.idx_mask));
+            }
+        }
+    }
+
+    // ---- rounds
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const u32 jlow = v & ((1u << (2 * r)) - 1u);
+        // stage A: position bit 2r, pairs (0,1) and (2,3), one twiddle w_S^(jlow * S / 2^(2r+1))
+        if (r == 0) {
+            // w = 1 and the loaded values are strict (< 2p, normalised): no multiplication
+            const Fe a0 = fe_add_lazy(x[0], x[1]), s0 = fe_sub_lazy<F>(x[0], x[1]);
+            const Fe a1 = fe_add_lazy(x[2], x[3]), s1 = fe_sub_lazy<F>(x[2], x[3]);
+            x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
+        } else {
+            const Fe w = fe_load(P.sub_tw + 2 * (u64)(jlow << (ls - 1 - 2 * r)));
+            const Fe t1 = fe_mul<F>(x[1], w), t3 = fe_mul<F>(x[3], w);
+            const Fe a0 = fe_add_lazy(x[0], t1), s0 = fe_sub_lazy<F>(x[0], t1);
+            const Fe a1 = fe_add_lazy(x[2], t3), s1 = fe_sub_lazy<F>(x[2], t3);
+            x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
+        }
+        // stage B: position bit 2r+1, pairs (0,2) and (1,3), twiddles w^(jlow) and w^(jlow + 2^(2r)) at this
+        // level; skipped in the last round of an odd digit (that bit is the column bit)
+        if (!(r == R - 1 && odd)) {
+            const u64 i0 = (u64)(jlow << (ls - 2 - 2 * r));
+            const Fe w0 = fe_load(P.sub_tw + 2 * i0);
+            const Fe w1 = fe_load(P.sub_tw + 2 * (i0 + (S >> 2)));
+            const Fe t2 = fe_mul<F>(x[2], w0), t3 = fe_mul<F>(x[3], w1);
+            const Fe a0 = fe_add_lazy(x[0], t2), s0 = fe_sub_lazy<F>(x[0], t2);
+            const Fe a1 = fe_add_lazy(x[1], t3), s1 = fe_sub_lazy<F>(x[1], t3);
+            x[0] = a0; x[2] = s0; x[1] = a1; x[3] = s1;
+        }
+        if (r == R - 1) break;
+        // ---- exchange: slot digit <-> lane field at physical bits (phi+1, phi)
+        constexpr int kPhiBase = LP - 4;
+        const int phi = kPhiBase - 2 * r;                 // compile-time after unrolling
+        const bool cross = phi + 1 > 5;
+        if (XCHG == kXchgDpp && !cross) {
+            // 4x4 transpose between the four lanes of a field, as two single-bit swaps:
+            // logical slot bit 0 <-> physical bit phi+1, slot bit 1 <-> physical bit phi.
+            switch (phi) {   // phi is even, 0..4
+                case 4:
+#pragma unroll
+                    for (int k = 0; k < kLimbs; ++k) {
+                        lane_swap<5>(x[0].l[k], x[1].l[k]); lane_swap<5>(x[2].l[k], x[3].l[k]);
+                        lane_swap<4>(x[0].l[k], x[2].l[k]); lane_swap<4>(x[1].l[k], x[3].l[k]);
+                    }
+                    break;
+                case 2:
+#pragma unroll
+                    for (int k = 0; k < kLimbs; ++k) {
+                        lane_swap<3>(x[0].l[k], x[1].l[k]); lane_swap<3>(x[2].l[k], x[3].l[k]);
+                        lane_swap<2>(x[0].l[k], x[2].l[k]); lane_swap<2>(x[1].l[k], x[3].l[k]);
+                    }
+                    break;
+                default:
+#pragma unroll
+                    for (int k = 0; k < kLimbs; ++k) {
+                        lane_swap<1>(x[0].l[k], x[1].l[k]); lane_swap<1>(x[2].l[k], x[3].l[k]);
+                        lane_swap<0>(x[0].l[k], x[2].l[k]); lane_swap<0>(x[1].l[k], x[3].l[k]);
+                    }
+                    break;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u32 a = gbase + (u32)e * U + (u ^ (rev2(e) << phi));
+#pragma unroll
+                for (int k = 0; k < kLimbs; ++k) lds[kUsesLds ? k : 0][kUsesLds ? a : 0] = x[e].l[k];
+            }
+            if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            const u32 pf = (u >> phi) & 3u;
+            const u32 rbase = gbase + rev2(pf) * U + (u & ~(3u << phi));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u32 a = rbase + ((rev2(e) ^ pf) << phi);
+#pragma unroll
+                for (int k = 0; k < kLimbs; ++k) x[e].l[k] = lds[kUsesLds ? k : 0][kUsesLds ? a : 0];
+            }
+            // An in-wave exchange only touches its wave's own window and DS operations of a wave execute
+            // in order; after a cross-wave exchange other waves may still be reading this wave's window
+            // when it writes again, so that case needs the second barrier.
+            if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- closing multiplication (inter-pass twiddle / scale / coset factor) or plain reduction, store
+    const Fe scale = fe_from_arg(P.scale);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // output digit k and column of slot e: extended position (e << LU) | v
+        const u32 col = odd ? ((g << 1) | ((u32)e >> 1)) : g;
+        const u32 kd = odd ? ((((u32)e & 1u) << LU) | v) : (((u32)e << LU) | v);
+        const u64 off = base_out + (u64)kd * P.stride_t_out + (u64)col * P.stride_c_out;
+        Fe y;
+        if (P.tw_mode != 0) {
+            const u64 K = K0 + (u64)kd * P.t_kw + (u64)col * P.c_kw, I = I0 + (u64)col * P.c_iw;
+            const u64 E = I * K;
+            const Fe f = (P.tw_mode == 1) ? fe_load(P.tw_lo + 2 * (E >> P.tw_shift))
+                                          : two_level_pow<F>(P.tw_lo, P.tw_hi, E & P.tw_mask);
+            y = fe_mul<F>(x[e], f);
+        } else if (P.scale_mode == 2) {
+            y = fe_mul<F>(x[e], fe_mul<F>(scale, two_level_pow<F>(P.sc_lo, P.sc_hi, off & P.idx_mask)));
+        } else if (P.scale_mode == 1) {
+            y = fe_mul<F>(x[e], scale);
+        } else {
+            y = fe_reduce_loose<F>(x[e]);
+        }
+        fe_store(P.dst + 2 * off, y);
+    }
+}
+
+}  // namespace acx

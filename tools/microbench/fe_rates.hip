@@ -1,10 +1,10 @@
 // tools/microbench/fe_rates.hip -- cycles per wave-level field operation on gfx950 (cost model for
-// kernels.cuh).  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../arithmetic-circuits_amd/csrc ...
+// kernels.hip.h).  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../arithmetic-circuits_amd/csrc ...
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 #include <algorithm>
-#include "fr.cuh"
+#include "fr.hip.h"
 using namespace acx;
 using F = Bn254Fr;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
