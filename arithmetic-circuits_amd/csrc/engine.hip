@@ -61,7 +61,9 @@ struct acx_ctx {
     std::map<std::pair<uint32_t, int>, uint4*> twiddles;  // (log_m, inverse) -> omega_M^j, j < M
     std::map<std::pair<uint32_t, int>, uint4*> tw_low;    // (log_n, inverse) -> omega_N^j, j < 1024
     std::map<std::tuple<uint32_t, uint64_t, int, uint32_t>, uint4*> tw_scaled;   // (log_m, count, inverse, log_n of folded 1/N)
+    std::map<std::pair<uint32_t, int>, uint4*> tw_limbs;  // (log_m, inverse) -> omega_M^j, j < M/2, limb form (k_ntt_r4)
     NttCfg ntt;
+    int coset_scaled = 0;                                  // coset_lo carries the 1/N of an inverse transform
     uint4* ntt_scratch = nullptr;                          // ping-pong buffer of the multi-pass NTT
     size_t ntt_scratch_bytes = 0;
     uint4* coset_lo = nullptr;                             // g^j (j < 1024), g^(1024 j): last shift used
@@ -236,6 +238,24 @@ int get_low_table(acx_ctx* c, uint32_t log_n, int inverse, uint4** out) {
     return ACX_OK;
 }
 
+// omega_M^j for j < M/2 in limb form (sub-transform twiddles of k_ntt_r4), cached.
+int get_limb_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
+    auto key = std::make_pair(log_m, inverse);
+    auto it = c->tw_limbs.find(key);
+    if (it != c->tw_limbs.end()) { *out = it->second; return ACX_OK; }
+    const uint64_t count = std::max<uint64_t>(1, (1ull << log_m) / 2);
+    uint4* tw = nullptr;
+    HIP_TRY(hipMalloc((void**)&tw, count * 48));
+    H256 w = c->hf.root_of_unity((int)log_m);
+    if (inverse) w = c->hf.inv(w);
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_limbs<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, tw,
+                                         count, dev_arg(c->hf, w)));
+    HIP_TRY(hipGetLastError());
+    c->tw_limbs[key] = tw;
+    *out = tw;
+    return ACX_OK;
+}
+
 // first * omega_M^j for j < count (M = 2^log_m; omega^-1 when inverse); first = 1 or 1/2^scaled_log_n.  Cached.
 int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, uint32_t scaled_log_n, uint4** out) {
     if (scaled_log_n == 0 && count == (1ull << log_m)) return get_pow_table(c, log_m, inverse, out);
@@ -257,16 +277,18 @@ int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, ui
 }
 
 // g^j (j < 1024) and g^(1024 j) (j < N/1024) for the coset factor; the last (g, log_n) is kept.
-int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, uint4** lo, uint4** hi) {
+// scaled: the low table carries the factor 1/2^log_n (closing multiplication of an inverse coset transform).
+int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scaled, uint4** lo, uint4** hi) {
     const uint64_t hi_count = log_n > 10 ? (1ull << (log_n - 10)) : 0;
-    if (!(c->coset_lo && c->coset_base == base_mont && c->coset_log_n == log_n)) {
+    if (!(c->coset_lo && c->coset_base == base_mont && c->coset_log_n == log_n && c->coset_scaled == scaled)) {
         HIP_TRY(hipStreamSynchronize(c->stream));   // previous users of the old tables are done
         if (c->coset_lo) (void)hipFree(c->coset_lo);
         if (c->coset_hi) (void)hipFree(c->coset_hi);
         c->coset_lo = c->coset_hi = nullptr;
         HIP_TRY(hipMalloc((void**)&c->coset_lo, 1024 * 32));
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(4), dim3(kBlock), 0, c->stream, c->coset_lo,
-                                             (u64)1024, dev_arg(c->hf, base_mont)));
+        const H256 first = scaled ? c->hf.inv(c->hf.from_u64(1ull << log_n)) : c->hf.one();
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(4), dim3(kBlock), 0, c->stream, c->coset_lo,
+                                             (u64)1024, dev_arg(c->hf, base_mont), dev_arg(c->hf, first)));
         if (hi_count) {
             HIP_TRY(hipMalloc((void**)&c->coset_hi, hi_count * 32));
             const H256 b1024 = c->hf.pow_u64(base_mont, 1024);
@@ -276,6 +298,7 @@ int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, uint4** 
         HIP_TRY(hipGetLastError());
         c->coset_base = base_mont;
         c->coset_log_n = log_n;
+        c->coset_scaled = scaled;
     }
     *lo = c->coset_lo;
     *hi = c->coset_hi;
@@ -383,7 +406,7 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
     uint4 *sc_lo = nullptr, *sc_hi = nullptr;
     if (shift_mont) {
         const H256 base = inverse ? hf.inv(*shift_mont) : *shift_mont;
-        ACX_TRY(get_coset_tables(c, base, log_n, &sc_lo, &sc_hi));
+        ACX_TRY(get_coset_tables(c, base, log_n, inverse ? 1 : 0, &sc_lo, &sc_hi));
     }
     // the r4 kernel can finish with a plain reduction: 1/N of an inverse transform is folded into the last
     // inter-pass twiddle table
@@ -395,7 +418,11 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         Q.src = first ? d : scratch;
         Q.dst = last ? d : scratch;
         Q.log_s = lg[p];
-        if (lg[p] > 0) { uint4* st = nullptr; ACX_TRY(get_pow_table(c, lg[p], inverse, &st)); Q.sub_tw = st; }
+        if (lg[p] > 0) {
+            uint4* st = nullptr;
+            if (r4) ACX_TRY(get_limb_table(c, lg[p], inverse, &st)); else ACX_TRY(get_pow_table(c, lg[p], inverse, &st));
+            Q.sub_tw = st;
+        }
         Q.idx_mask = N - 1;
         Q.sc_lo = sc_lo; Q.sc_hi = sc_hi;
         const uint64_t S = 1ull << lg[p];
@@ -467,7 +494,8 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         if (first && !inverse && shift_mont) Q.scale_on_load = 1;
         if (last) {
             // the closing multiplication: 1 (forward), 1/N (inverse), 1/N * g^-k (inverse coset)
-            const H256 s = inverse ? hf.inv(hf.from_u64(N)) : hf.one();
+            // (the coset tables of an inverse transform already carry 1/N)
+            const H256 s = (inverse && !shift_mont) ? hf.inv(hf.from_u64(N)) : hf.one();
             Q.scale = dev_arg(hf, s);
             Q.scale_mode = (inverse && shift_mont) ? 2 : 1;
             if (r4 && Q.scale_mode == 1 && (!inverse || fold_scale)) Q.scale_mode = 0;   // nothing left to multiply by
@@ -831,6 +859,7 @@ void acx_ctx_destroy(acx_ctx* c) {
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto& kv : c->tw_low) (void)hipFree(kv.second);
     for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
+    for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
     if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
     if (c->coset_lo) (void)hipFree(c->coset_lo);
     if (c->coset_hi) (void)hipFree(c->coset_hi);
@@ -854,9 +883,11 @@ int acx_ctx_set_root(acx_ctx* c, uint32_t two_adicity, const acx_fr* omega) {
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto& kv : c->tw_low) (void)hipFree(kv.second);
     for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
+    for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
     c->twiddles.clear();
     c->tw_low.clear();
     c->tw_scaled.clear();
+    c->tw_limbs.clear();
     c->hf.set_omega_max(w, (int)two_adicity);
     return ACX_OK;
 }

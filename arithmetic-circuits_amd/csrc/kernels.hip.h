@@ -315,6 +315,18 @@ __global__ __launch_bounds__(kBlock) void k_pow_table_scaled(uint4* __restrict__
         fe_store(tw + 2 * j, fe_mul<F>(fe_pow<F>(base, j), first));
 }
 
+// limb-form table for k_ntt_r4: entry j = 3 x uint4 holding the nine 29-bit limbs of base^j (no unpacking in the kernel)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_pow_table_limbs(uint4* __restrict__ tw, u64 count, FeArg base_arg) {
+    const Fe base = fe_from_arg(base_arg);
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < count; j += (u64)gridDim.x * kBlock) {
+        const Fe w = fe_pow<F>(base, j);
+        tw[3 * j] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
+        tw[3 * j + 1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
+        tw[3 * j + 2] = make_uint4(w.l[8], 0u, 0u, 0u);
+    }
+}
+
 // ---- K3/K4: tiled multi-pass NTT ---------------------------------------------------------------
 // A length-N transform is factored N = N_1 * ... * N_P (P <= 4, every N_p <= 256).  Pass p runs
 // all the length-N_p sub-transforms over digit p of the index; a workgroup owns a tile of

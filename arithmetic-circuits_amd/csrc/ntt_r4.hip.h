@@ -80,9 +80,62 @@ __device__ __forceinline__ void lane_swap(u32& lo, u32& hi) {
     }
 }
 
+// sub-transform twiddles in limb form: entry j = 3 x uint4 = the nine 29-bit limbs of w_S^j (strict) + padding
+__device__ __forceinline__ Fe fe_load_limbs(const uint4* __restrict__ tab, u64 idx) {
+    const uint4 a = gload(tab + 3 * idx), b = gload(tab + 3 * idx + 1), c = gload(tab + 3 * idx + 2);
+    Fe r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x;
+    return r;
+}
+
+// One round on the four slots: stage A pairs (0,1),(2,3) with twiddle wA, stage B pairs (0,2),(1,3) with
+// twiddles wB0 / wB1.  Stage A leaves its sums uncarried (limbs < 2^31: fe_mul's left operand and the
+// carrying add/sub of stage B take them); stage B carries.  TRIV (wave-uniform): wA = wB0 = 1, so those
+// three products are replaced by the multiplication-free reduction.
+template <class F, bool TRIV>
+__device__ __forceinline__ void r4_round(Fe (&x)[4], const uint4* __restrict__ tw, u64 iA, u64 iB0, u64 iB1, bool stage_b) {
+    {
+        Fe t1, t3;
+        if (TRIV) {
+            t1 = fe_reduce_loose<F>(x[1]); t3 = fe_reduce_loose<F>(x[3]);
+        } else {
+            const Fe w = fe_load_limbs(tw, iA);
+            t1 = fe_mul<F>(x[1], w); t3 = fe_mul<F>(x[3], w);
+        }
+        const Fe a0 = fe_add_lazy<false>(x[0], t1), s0 = fe_sub_lazy<F, false>(x[0], t1);
+        const Fe a1 = fe_add_lazy<false>(x[2], t3), s1 = fe_sub_lazy<F, false>(x[2], t3);
+        x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
+    }
+    if (stage_b) {
+        const Fe w1 = fe_load_limbs(tw, iB1);
+        Fe t2;
+        if (TRIV) t2 = fe_reduce_loose<F>(x[2]);
+        else t2 = fe_mul<F>(x[2], fe_load_limbs(tw, iB0));
+        const Fe t3 = fe_mul<F>(x[3], w1);
+        const Fe a0 = fe_add_lazy(x[0], t2), s0 = fe_sub_lazy<F>(x[0], t2);
+        const Fe a1 = fe_add_lazy(x[1], t3), s1 = fe_sub_lazy<F>(x[1], t3);
+        x[0] = a0; x[2] = s0; x[1] = a1; x[3] = s1;
+    }
+}
+
+// 4x4 transpose between the four lanes of an in-wave field at physical bits (PHI+1, PHI) without LDS:
+// logical slot bit 0 <-> lane bit PHI+1, slot bit 1 <-> lane bit PHI.
+template <int PHI>
+__device__ __forceinline__ void r4_xchg_dpp(Fe (&x)[4]) {
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        lane_swap<PHI + 1>(x[0].l[k], x[1].l[k]); lane_swap<PHI + 1>(x[2].l[k], x[3].l[k]);
+        lane_swap<PHI>(x[0].l[k], x[2].l[k]);     lane_swap<PHI>(x[1].l[k], x[3].l[k]);
+    }
+}
+
 // ---- the pass kernel ---------------------------------------------------------------------------------
 // LP: even number of extended position bits of a thread group (sub-transform digit rounded up to
 // even); LG: log2(thread groups per workgroup).  blockDim.x = 2^(LP-2+LG), tile = 2^(LP+LG) elements.
+// The rounds are a real loop (one body in the instruction cache, ~1.5k instructions, instead of a
+// 12k-instruction straight line), and so are the four closing multiplications (slots rotate through x[0]).
 template <class F, int LP, int LG, int XCHG>
 __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
     constexpr int LU = LP - 2;
@@ -117,12 +170,12 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
     Fe x[4];
     {
         const u32 col = (g << odd) | (u & odd);
-        const u64 cbase = base_in + (u64)col * P.stride_c_in;
+        const u64 cbase = base_in + (u64)col * P.stride_c_in + (u64)(u >> odd) * P.stride_t_in;
+        const u64 estride = (u64)P.stride_t_in << (ls - 2);
         uint4 raw[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const u32 d = (rev2(e) << (ls - 2)) | (u >> odd);
-            const uint4* p = P.src + 2 * (cbase + (u64)d * P.stride_t_in);
+            const uint4* p = P.src + 2 * (cbase + (u64)rev2(e) * estride);
             raw[2 * e] = gload(p);
             raw[2 * e + 1] = gload(p + 1);
         }
@@ -131,73 +184,41 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
             const u32 w[8] = {raw[2 * e].x, raw[2 * e].y, raw[2 * e].z, raw[2 * e].w,
                               raw[2 * e + 1].x, raw[2 * e + 1].y, raw[2 * e + 1].z, raw[2 * e + 1].w};
             x[e] = fe_unpack(w);
-            if (P.scale_on_load) {
-                const u32 d = (rev2(e) << (ls - 2)) | (u >> odd);
-                const u64 off = cbase + (u64)d * P.stride_t_in;
-                x[e] = fe_mul<F>(x[e], two_level_pow<F>(P.sc_lo, P.sc_hi, off & P.idx_mask));
+        }
+        if (P.scale_on_load) {               // coset pre-multiplication of a forward transform
+#pragma unroll 1
+            for (u32 e = 0; e < 4; ++e) {
+                const u64 off = cbase + (u64)rev2(e) * estride;
+                const Fe y = fe_mul<F>(x[0], two_level_pow<F>(P.sc_lo, P.sc_hi, off & P.idx_mask));
+                x[0] = x[1]; x[1] = x[2]; x[2] = x[3]; x[3] = y;
             }
         }
     }
 
-    // ---- rounds
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const u32 jlow = v & ((1u << (2 * r)) - 1u);
-        // stage A: position bit 2r, pairs (0,1) and (2,3), one twiddle w_S^(jlow * S / 2^(2r+1))
-        if (r == 0) {
-            // w = 1 and the loaded values are strict (< 2p, normalised): no multiplication
-            const Fe a0 = fe_add_lazy(x[0], x[1]), s0 = fe_sub_lazy<F>(x[0], x[1]);
-            const Fe a1 = fe_add_lazy(x[2], x[3]), s1 = fe_sub_lazy<F>(x[2], x[3]);
-            x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
-        } else {
-            const Fe w = fe_load(P.sub_tw + 2 * (u64)(jlow << (ls - 1 - 2 * r)));
-            const Fe t1 = fe_mul<F>(x[1], w), t3 = fe_mul<F>(x[3], w);
-            const Fe a0 = fe_add_lazy(x[0], t1), s0 = fe_sub_lazy<F>(x[0], t1);
-            const Fe a1 = fe_add_lazy(x[2], t3), s1 = fe_sub_lazy<F>(x[2], t3);
-            x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
+    // ---- round 0: stage A has w = 1 on strict inputs (no multiplication), stage B has w = 1 and w_4
+    {
+        const Fe a0 = fe_add_lazy<false>(x[0], x[1]), s0 = fe_sub_lazy<F, false>(x[0], x[1]);
+        const Fe a1 = fe_add_lazy<false>(x[2], x[3]), s1 = fe_sub_lazy<F, false>(x[2], x[3]);
+        x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
+        if (!(R == 1 && odd)) {
+            const Fe t2 = fe_reduce_loose<F>(x[2]);
+            const Fe t3 = fe_mul<F>(x[3], fe_load_limbs(P.sub_tw, (u64)(S >> 2)));
+            const Fe b0 = fe_add_lazy(x[0], t2), d0 = fe_sub_lazy<F>(x[0], t2);
+            const Fe b1 = fe_add_lazy(x[1], t3), d1 = fe_sub_lazy<F>(x[1], t3);
+            x[0] = b0; x[2] = d0; x[1] = b1; x[3] = d1;
         }
-        // stage B: position bit 2r+1, pairs (0,2) and (1,3), twiddles w^(jlow) and w^(jlow + 2^(2r)) at this
-        // level; skipped in the last round of an odd digit (that bit is the column bit)
-        if (!(r == R - 1 && odd)) {
-            const u64 i0 = (u64)(jlow << (ls - 2 - 2 * r));
-            const Fe w0 = fe_load(P.sub_tw + 2 * i0);
-            const Fe w1 = fe_load(P.sub_tw + 2 * (i0 + (S >> 2)));
-            const Fe t2 = fe_mul<F>(x[2], w0), t3 = fe_mul<F>(x[3], w1);
-            const Fe a0 = fe_add_lazy(x[0], t2), s0 = fe_sub_lazy<F>(x[0], t2);
-            const Fe a1 = fe_add_lazy(x[1], t3), s1 = fe_sub_lazy<F>(x[1], t3);
-            x[0] = a0; x[2] = s0; x[1] = a1; x[3] = s1;
-        }
-        if (r == R - 1) break;
-        // ---- exchange: slot digit <-> lane field at physical bits (phi+1, phi)
-        constexpr int kPhiBase = LP - 4;
-        const int phi = kPhiBase - 2 * r;                 // compile-time after unrolling
-        const bool cross = phi + 1 > 5;
+    }
+
+    // ---- exchange + round r, r = 1 .. R-1
+#pragma unroll 1
+    for (int r = 1; r < R; ++r) {
+        // exchange: slot digit <-> lane field at physical bits (phi+1, phi)
+        const int phi = LP - 2 - 2 * r;
+        const bool cross = phi > 4;
         if (XCHG == kXchgDpp && !cross) {
-            // 4x4 transpose between the four lanes of a field, as two single-bit swaps:
-            // logical slot bit 0 <-> physical bit phi+1, slot bit 1 <-> physical bit phi.
-            switch (phi) {   // phi is even, 0..4
-                case 4:
-#pragma unroll
-                    for (int k = 0; k < kLimbs; ++k) {
-                        lane_swap<5>(x[0].l[k], x[1].l[k]); lane_swap<5>(x[2].l[k], x[3].l[k]);
-                        lane_swap<4>(x[0].l[k], x[2].l[k]); lane_swap<4>(x[1].l[k], x[3].l[k]);
-                    }
-                    break;
-                case 2:
-#pragma unroll
-                    for (int k = 0; k < kLimbs; ++k) {
-                        lane_swap<3>(x[0].l[k], x[1].l[k]); lane_swap<3>(x[2].l[k], x[3].l[k]);
-                        lane_swap<2>(x[0].l[k], x[2].l[k]); lane_swap<2>(x[1].l[k], x[3].l[k]);
-                    }
-                    break;
-                default:
-#pragma unroll
-                    for (int k = 0; k < kLimbs; ++k) {
-                        lane_swap<1>(x[0].l[k], x[1].l[k]); lane_swap<1>(x[2].l[k], x[3].l[k]);
-                        lane_swap<0>(x[0].l[k], x[2].l[k]); lane_swap<0>(x[1].l[k], x[3].l[k]);
-                    }
-                    break;
-            }
+            if (phi == 4) r4_xchg_dpp<4>(x);
+            else if (phi == 2) r4_xchg_dpp<2>(x);
+            else r4_xchg_dpp<0>(x);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -219,30 +240,39 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
             // when it writes again, so that case needs the second barrier.
             if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         }
+        // round r: twiddle exponents from the processed position bits jlow = v mod 4^r
+        const u32 jlow = v & ((1u << (2 * r)) - 1u);
+        const bool stage_b = !(r == R - 1 && odd);
+        const u64 iA = (u64)jlow << (ls - 1 - 2 * r);
+        const u64 iB0 = stage_b ? ((u64)jlow << (ls - 2 - 2 * r)) : 0;
+        if (__ballot(jlow != 0) == 0) r4_round<F, true>(x, P.sub_tw, iA, iB0, iB0 + (S >> 2), stage_b);
+        else r4_round<F, false>(x, P.sub_tw, iA, iB0, iB0 + (S >> 2), stage_b);
     }
 
-    // ---- closing multiplication (inter-pass twiddle / scale / coset factor) or plain reduction, store
+    // ---- closing: inter-pass twiddle / scale / coset factor (one multiplication) or plain reduction; store.
+    // Slot e = output digit (e << LU) | v; the slots rotate through x[0] so that the loop body exists once.
     const Fe scale = fe_from_arg(P.scale);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        // output digit k and column of slot e: extended position (e << LU) | v
-        const u32 col = odd ? ((g << 1) | ((u32)e >> 1)) : g;
-        const u32 kd = odd ? ((((u32)e & 1u) << LU) | v) : (((u32)e << LU) | v);
+#pragma unroll 1
+    for (u32 e = 0; e < 4; ++e) {
+        const Fe cur = x[0];
+        x[0] = x[1]; x[1] = x[2]; x[2] = x[3];
+        const u32 col = odd ? ((g << 1) | (e >> 1)) : g;
+        const u32 kd = odd ? (((e & 1u) << LU) | v) : ((e << LU) | v);
         const u64 off = base_out + (u64)kd * P.stride_t_out + (u64)col * P.stride_c_out;
-        Fe y;
-        if (P.tw_mode != 0) {
+        Fe f = scale;
+        bool mul = true;
+        if (P.tw_mode == 1) {
             const u64 K = K0 + (u64)kd * P.t_kw + (u64)col * P.c_kw, I = I0 + (u64)col * P.c_iw;
-            const u64 E = I * K;
-            const Fe f = (P.tw_mode == 1) ? fe_load(P.tw_lo + 2 * (E >> P.tw_shift))
-                                          : two_level_pow<F>(P.tw_lo, P.tw_hi, E & P.tw_mask);
-            y = fe_mul<F>(x[e], f);
-        } else if (P.scale_mode == 2) {
-            y = fe_mul<F>(x[e], fe_mul<F>(scale, two_level_pow<F>(P.sc_lo, P.sc_hi, off & P.idx_mask)));
-        } else if (P.scale_mode == 1) {
-            y = fe_mul<F>(x[e], scale);
-        } else {
-            y = fe_reduce_loose<F>(x[e]);
+            f = fe_load(P.tw_lo + 2 * ((I * K) >> P.tw_shift));
+        } else if (P.tw_mode == 2 || P.scale_mode == 2) {
+            const u64 K = K0 + (u64)kd * P.t_kw + (u64)col * P.c_kw, I = I0 + (u64)col * P.c_iw;
+            const bool tw = P.tw_mode == 2;
+            f = two_level_pow<F>(tw ? P.tw_lo : P.sc_lo, tw ? P.tw_hi : P.sc_hi, tw ? ((I * K) & P.tw_mask) : (off & P.idx_mask));
+        } else if (P.scale_mode == 0) {
+            mul = false;
         }
+        Fe y;
+        if (mul) y = fe_mul<F>(cur, f); else y = fe_reduce_loose<F>(cur);
         fe_store(P.dst + 2 * off, y);
     }
 }
