@@ -375,8 +375,16 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
             for (int i = 0; i < P; ++i) lg[i] = cfg.digits[i];
         } else if (log_n <= 12 && (log_n % 2 == 0 || batch_pow2 >= 2)) {
             P = 1; lg[0] = log_n;
+        } else if (log_n <= 12) {
+            P = 2; lg[0] = log_n - 5; lg[1] = 5;          // odd digit, single transform: the 5-bit pass brings the column pairs
+        } else if (log_n <= 17) {
+            P = 2; lg[0] = log_n - 8; lg[1] = 8;          // measured best (tools/ntt_sweep.sh, profiles/r02_ntt_plans.txt)
+        } else if (log_n <= 20) {
+            P = 2; lg[0] = log_n % 2 ? 7 : 8; lg[1] = log_n - lg[0];
+        } else if (log_n <= 28) {
+            P = 3; lg[0] = log_n - 16; lg[1] = 8; lg[2] = 8;
         } else {
-            P = log_n <= 24 ? 2 : 3;
+            P = 3;
             for (int p = 0; p < P; ++p) lg[p] = log_n / P + ((uint32_t)p < log_n % P ? 1 : 0);
         }
         for (int p = 0; p < P; ++p) if (lg[p] < 5 || lg[p] > 12) r4 = false;
@@ -435,6 +443,8 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
             lp = (int)(lg[p] + odd);
             const uint64_t cap = std::max<uint64_t>(1ull << cfg.tile_log, S << odd);
             uint64_t t_want = std::min<uint64_t>(cap / S, col_avail);
+            // small transforms: prefer more, smaller tiles until the grid fills the chip four times over
+            while (t_want > (1ull << odd) && batch * N / (S * t_want) < 4ull * (uint64_t)c->n_cu) t_want >>= 1;
             if (t_want < (1ull << odd)) return fail(ACX_ERR_UNSUPPORTED, "NTT plan: odd digit needs two columns");
             lgrp = r4_pick_lg(lp, (int)ilog2(t_want) - (int)odd);
             if (lgrp < 0) return fail(ACX_ERR_UNSUPPORTED, "NTT plan: no kernel instance");

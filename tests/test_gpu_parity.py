@@ -504,6 +504,9 @@ def test_gpu_witness_generation_equals_host(request, acx, field, seed):
         want_w, want_as = circ.eval(arr)
         got_w, got_as = r.eval_witness(arr)
         assert np.array_equal(got_w, want_w) and np.array_equal(got_as, want_as)
+        # ... and against the ORACLE's literal evalArithCircuit fold (not only the product's own host evaluator)
+        oracle_w = H.qapset_to_flat(R.generate_assignment(gates, inp, p), H.circuit_dims(gates), p)
+        assert acx.fr_to_ints(got_w) == oracle_w
         assert r.verify_resident() == (True, 0, 2**64 - 1)
         assert r.verify(want_w)[0]
 
@@ -516,6 +519,16 @@ def test_gpu_witness_generation_mulgraph_and_errors(request, acx):
     w, _ = r.eval_witness(s.inputs)
     assert np.array_equal(w, s.witness())
     assert r.verify_resident()[0]
+    # oracle link at this size: the C oracle's residuals of the GPU-generated witness are all zero, and a
+    # witness recomputed gate by gate with Python integers from the exported rows agrees on a sample of gates
+    orc = _orc(request, "bn254")
+    _, nbad, _ = orc.r1cs_residuals(r.n, r.m, *s.rows(), w, want_residuals=False, nthreads=8)
+    assert nbad == 0
+    A, B, _C = s.rows()
+    wi = acx.fr_to_ints(w)
+    for g in (0, 1, 17, 4095, (1 << 14) - 1):
+        dot = lambda M: sum(int(v) * wi[int(c)] for c, v in zip(M[1][M[0][g]:M[0][g + 1]], acx.fr_to_ints(M[2][M[0][g]:M[0][g + 1]]))) % ctx.p
+        assert wi[int(_C[1][_C[0][g]])] == dot(A) * dot(B) % ctx.p
     # partially present inputs: absent keys read as 0 (fromMaybe 0, src/Circuit/Affine.hs:84)
     pres = np.ones(64, dtype=np.uint8)
     pres[3] = 0
@@ -689,3 +702,71 @@ def test_sharded_layer_two_ranks_on_one_device():
     out = subprocess.run(cmd, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "dist gpu worker ok 2" in out.stdout
+
+
+# ------------------------------------------------------------------ configs[2] / configs[4] at their stated size
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+def test_qap_h_and_columns_2_20_vs_oracle(request, acx, field):
+    """configs[2] (and its configs[4] field swap) at N = 2^20: the 7-NTT h(x) pipeline of verificationWitness
+    (src/QAP.hs:309-327) and a batch of 64 createPolynomialsFFT column interpolations (src/QAP.hs:512-525),
+    every coefficient against the C oracle; plus the full 2^20-row residual vector on a corrupted witness."""
+    ctx, orc = _ctx(request, field), _orc(request, field)
+    synth = __import__("importlib").import_module("arithmetic-circuits_amd.synth")
+    n = 1 << 20
+    s = synth.mulgraph(n, field=field, seed=0xC3 + len(field))
+    mats, w = s.rows(), s.witness()
+    r = s.circuit.to_r1cs(ctx)
+    assert r.log_n == 20
+    h, ok = r.qap_h(w)
+    want_h, want_ok = orc.qap_h(n, r.m, 20, *mats, w, nthreads=64)
+    assert ok and want_ok
+    hl = h.shape[0]
+    assert hl <= n - 1 and np.array_equal(h, want_h[:hl]) and not want_h[hl:].any()
+    # zero-knowledge variant (verificationWitnessZk) at the same size
+    delta = [3, 5, 7]
+    hz, okz = r.qap_h(w, delta=delta)
+    want_hz, _ = orc.qap_h(n, r.m, 20, *mats, w, delta=delta, nthreads=64)
+    assert okz and np.array_equal(hz, want_hz[:hz.shape[0]]) and not want_hz[hz.shape[0]:].any()
+    # 64 columns of A starting inside the intermediate wires (dense enough to matter)
+    w0 = 1 + 1024 + 4000
+    cols, lens = r.qap_columns(0, w0, 64)
+    want_cols = orc.qap_columns(n, 20, mats[0], w0, 64, nthreads=64)
+    assert np.array_equal(cols.reshape(want_cols.shape), want_cols)
+    # residual vector of a corrupted witness, all 2^20 rows
+    bad = w.copy()
+    for k in (5, 1 + 1024 + 12345, r.m - 2):
+        bad[k, 0] ^= np.uint64(1)
+    want_res, nbad, first = orc.r1cs_residuals(n, r.m, *mats, bad, nthreads=64)
+    assert nbad > 0 and np.array_equal(r.residuals(bad), want_res)
+    assert r.verify(bad) == (False, nbad, first)
+
+
+def test_ntt_dense_2_24_vs_oracle(request, acx):
+    """configs[3]'s transform size on one GPU: a dense 2^24-point forward NTT and inverse coset NTT, every
+    output element against the C oracle (64 host threads: a few seconds each)."""
+    ctx, orc = _ctx(request, "bn254"), _orc(request, "bn254")
+    synth = __import__("importlib").import_module("arithmetic-circuits_amd.synth")
+    ln = 24
+    x = synth.random_fr(1 << ln, 24, 1)
+    got = ctx.ntt(x, ln)
+    assert np.array_equal(got, orc.ntt(x, ln, nthreads=64))
+    assert np.array_equal(ctx.ntt(got, ln, inverse=True), x)
+    g = orc.generator
+    assert np.array_equal(ctx.ntt(x, ln, inverse=True, shift=g), orc.ntt(x, ln, inverse=True, shift=g, nthreads=64))
+
+
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("log_n", [10, 11, 12, 13, 15, 17, 18, 19, 21, 22])
+def test_ntt_every_plan_vs_oracle(request, acx, field, log_n):
+    """Every digit plan of the register-resident NTT kernel (single pass, odd digits with column pairs,
+    two and three passes): forward, inverse, coset forward, coset inverse; batch 1 and (small sizes) 3."""
+    ctx, orc = _ctx(request, field), _orc(request, field)
+    synth = __import__("importlib").import_module("arithmetic-circuits_amd.synth")
+    for batch in ((1, 3, 4) if log_n <= 13 else (1,)):
+        xs = synth.random_fr(batch << log_n, 100 + log_n, batch, field)
+        want = lambda **kw: np.concatenate([orc.ntt(xs[b << log_n:(b + 1) << log_n], log_n, nthreads=32, **kw) for b in range(batch)])
+        assert np.array_equal(ctx.ntt(xs, log_n), want())
+        assert np.array_equal(ctx.ntt(xs, log_n, inverse=True), want(inverse=True))
+        sh = 0x1234567 + log_n
+        assert np.array_equal(ctx.ntt(xs, log_n, shift=sh), want(shift=sh))
+        assert np.array_equal(ctx.ntt(xs, log_n, inverse=True, shift=sh), want(inverse=True, shift=sh))

@@ -13,6 +13,7 @@ import sys
 GROUPS = {
     "sq": "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD",
     "sq2": "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE",
+    "ic": "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES",
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum",
     # vector-memory path (TA -> TCP(L1) -> TCC(L2)); <= 4 counters of one block per pass
@@ -34,6 +35,7 @@ def main():
     ap.add_argument("--groups", default="sq,fetch,write")
     ap.add_argument("--match", default="")
     ap.add_argument("--pass-timeout", type=int, default=240)
+    ap.add_argument("--keep-db", action="store_true", help="keep the rocprofv3 databases (tens of MB) next to summary.txt")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
@@ -77,6 +79,10 @@ def main():
                     parts.append(f"{key}={v:.4g}")
             lines.append("    " + "  ".join(parts))
     text = "\n".join(lines)
+    if not a.keep_db:
+        import shutil
+        for name, _ in runs:
+            shutil.rmtree(os.path.join(a.out, name), ignore_errors=True)
     print(text)
     open(os.path.join(a.out, "summary.txt"), "w").write("cmd: " + " ".join(cmd) + "\n" + text + "\n")
 
