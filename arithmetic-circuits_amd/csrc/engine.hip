@@ -107,6 +107,7 @@ struct acx_r1cs {
     uint4* ev_mul = nullptr;             // per plan item: the Mul gate's record (k_eval_level)
     bool has_csc = false;
     uint4* d_w = nullptr;  // witness staging, m elements
+    uint4* qh = nullptr;   // h(x) pipeline scratch, 5N elements (allocated on first use)
 };
 
 struct acx_batch {
@@ -737,7 +738,8 @@ void free_r1cs_device(acx_r1cs* r) {
     if (r->ev_kind) (void)hipFree(r->ev_kind);
     r->ev_items = r->ev_row = r->ev_wire_ofs = r->ev_wires = nullptr; r->ev_kind = nullptr;
     if (r->d_w) (void)hipFree(r->d_w);
-    r->perm = nullptr; r->long_rows = nullptr; r->d_w = nullptr;
+    if (r->qh) (void)hipFree(r->qh);
+    r->perm = nullptr; r->long_rows = nullptr; r->d_w = nullptr; r->qh = nullptr;
 }
 
 int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3], acx_r1cs** out) {
@@ -1236,57 +1238,77 @@ int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out) {
     return download_elements(c, res.as<uint4>(), r->n, out, res.as<uint4>());
 }
 
+// verificationWitnessZk on device-resident data (caller holds ctx->mu): residual dots -> 3 iNTT -> 3 coset NTT ->
+// pointwise -> coset iNTT (+ the zero-knowledge terms).  d_h receives N+1 dev elements, not stripped.
+static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4* d_h, unsigned long long* d_result) {
+    acx_ctx* c = r->ctx;
+    const HostField& hf = c->hf;
+    if ((int)r->log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
+    const uint64_t N = 1ull << r->log_n;
+    if (!r->qh) HIP_TRY(hipMalloc((void**)&r->qh, 5 * N * 32));      // dots (3N) + kept L0, R0 (2N): lives with the system
+    uint4* d = r->qh;
+    uint4* keep = d + 6 * N;
+    HIP_TRY(hipMemsetAsync(d, 0, 3 * N * 32, c->stream));  // rows n..N-1 are the zero padding
+    ACX_TRY(launch_residual(r, d_w, 0, d_result, nullptr, d, N));
+    // evaluations on <omega> -> coefficients of L0, R0, O0
+    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr));
+    const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
+    if (zk) HIP_TRY(hipMemcpyAsync(keep, d, 2 * N * 32, hipMemcpyDeviceToDevice, c->stream));
+    // coset evaluations, shift = multiplicative generator g (g^N != 1)
+    const H256 g = hf.generator();
+    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, &g));
+    const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, c->stream, (const uint4*)d,
+                                         (const uint4*)(d + 2 * N), (const uint4*)(d + 4 * N), d_h, N, dev_arg(hf, zinv)));
+    ACX_TRY(ntt_dev_locked(c, d_h, r->log_n, 1, 1, &g));
+    if (zk) {
+        // (L0+d1 T)(R0+d2 T) - (O0+d3 T) = T * (h0 + d1 R0 + d2 L0 + d1 d2 T - d3),  T = x^N - 1
+        const uint4* L0 = keep;
+        const uint4* R0 = L0 + 2 * N;
+        const H256 d12 = hf.mul(dl[0], dl[1]);
+        DISPATCH_FIELD(c, {
+            hipLaunchKernelGGL((k_axpy2<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, c->stream, d_h, R0, L0, N,
+                               dev_arg(hf, dl[0]), dev_arg(hf, dl[1]));
+            hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, c->stream, d_h, N, dev_arg(hf, hf.add(d12, dl[2])), dev_arg(hf, d12));
+        });
+    } else {
+        HIP_TRY(hipMemsetAsync(d_h + 2 * N, 0, 32, c->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int acx_qap_h_dev(acx_r1cs* r, const void* d_witness, const acx_fr* delta, void* d_h, uint64_t* d_result) {
+    if (!r || !d_witness || !d_h || !d_result) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    acx_ctx* c = r->ctx;
+    H256 dl[3];
+    if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], c->hf, dl[k]));
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    return qap_h_dev_locked(r, (const uint4*)d_witness, delta ? dl : nullptr, (uint4*)d_h, (unsigned long long*)d_result);
+}
+
 int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok) {
     if (!r || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
     const HostField& hf = c->hf;
     if ((int)r->log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
+    H256 dl[3];
+    if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], hf, dl[k]));
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t N = 1ull << r->log_n;
-    DevBuf dots, keep;
-    ACX_TRY(dots.alloc(3 * N * 32));
-    uint4* d = dots.as<uint4>();
-    HIP_TRY(hipMemsetAsync(d, 0, 3 * N * 32, c->stream));  // rows n..N-1 are the zero padding
-    uint64_t bad = 0;
-    ACX_TRY(verify_common(r, witness, &bad, nullptr, nullptr, d, N));
-    *ok = bad == 0;
-    // evaluations on <omega> -> coefficients of L0, R0, O0
-    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr));
-    H256 dl[3];
-    bool zk = false;
-    if (delta) {
-        for (int k = 0; k < 3; ++k) { ACX_TRY(read_h256(&delta[k], hf, dl[k])); zk = zk || !dl[k].is_zero(); }
-    }
-    if (zk) {
-        ACX_TRY(keep.alloc(2 * N * 32));
-        HIP_TRY(hipMemcpyAsync(keep.p, d, 2 * N * 32, hipMemcpyDeviceToDevice, c->stream));
-    }
-    // coset evaluations, shift = multiplicative generator g (g^N != 1)
-    const H256 g = hf.generator();
-    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, &g));
-    const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, c->stream, d,
-                                         (const uint4*)(d + 2 * N), (const uint4*)(d + 4 * N), N, dev_arg(hf, zinv)));
-    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 1, 1, &g));
-    if (zk) {
-        // (L0+d1 T)(R0+d2 T) - (O0+d3 T) = T * (h0 + d1 R0 + d2 L0 + d1 d2 T - d3),  T = x^N - 1
-        const uint4* L0 = keep.as<uint4>();
-        const uint4* R0 = L0 + 2 * N;
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy2<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, c->stream, d, R0, L0, N,
-                                             dev_arg(hf, dl[0]), dev_arg(hf, dl[1])));
-    }
-    HIP_TRY(hipGetLastError());
-    ACX_TRY(download_elements(c, d, N, out_h, d + 2 * N));
-    std::memset(out_h[N].b, 0, 32);
-    if (zk) {
-        const H256 d12 = hf.mul(dl[0], dl[1]);
-        H256 h0;
-        ACX_TRY(read_h256(&out_h[0], hf, h0));
-        h0 = hf.sub(hf.sub(h0, d12), dl[2]);
-        write_h256(&out_h[0], hf, h0);
-        write_h256(&out_h[N], hf, d12);
-    }
+    DevBuf hbuf;
+    ACX_TRY(hbuf.alloc(2 * (N + 1) * 32));                 // h (N+1) + conversion scratch
+    uint4* d_h = hbuf.as<uint4>();
+    ACX_TRY(upload_elements(c, witness, r->m, r->d_w));
+    const unsigned long long init[2] = {0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(c->d_result, init, 16, hipMemcpyHostToDevice, c->stream));
+    ACX_TRY(qap_h_dev_locked(r, r->d_w, delta ? dl : nullptr, d_h, c->d_result));
+    unsigned long long res[2];
+    HIP_TRY(hipMemcpyAsync(res, c->d_result, 16, hipMemcpyDeviceToHost, c->stream));
+    ACX_TRY(download_elements(c, d_h, N + 1, out_h, d_h + 2 * (N + 1)));
+    *ok = res[0] == 0;
     uint64_t len = N + 1;
     static const uint8_t zero32[32] = {0};
     while (len > 0 && std::memcmp(out_h[len - 1].b, zero32, 32) == 0) --len;

@@ -469,14 +469,24 @@ __global__ __launch_bounds__(kBlock) void k_twiddle_tile(uint4* __restrict__ dat
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5: h on the coset: a[i] = (a[i]*b[i] - c[i]) * zinv   (src/QAP.hs:325-327 in evaluation form)
+// K5: h on the coset: out[i] = (a[i]*b[i] - c[i]) * zinv   (src/QAP.hs:325-327 in evaluation form)
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_pointwise_h(uint4* __restrict__ a, const uint4* __restrict__ b,
-                                                       const uint4* __restrict__ c, u64 n, FeArg zinv_arg) {
+__global__ __launch_bounds__(kBlock) void k_pointwise_h(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                       const uint4* __restrict__ c, uint4* __restrict__ out, u64 n,
+                                                       FeArg zinv_arg) {
     const Fe zinv = fe_from_arg(zinv_arg);
     for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
         const Fe t = fe_sub<F>(fe_mul<F>(fe_load(a + 2 * i), fe_load(b + 2 * i)), fe_load(c + 2 * i));
-        fe_store(a + 2 * i, fe_mul<F>(t, zinv));
+        fe_store(out + 2 * i, fe_mul<F>(t, zinv));
+    }
+}
+
+// the two scalar corrections of the zero-knowledge quotient: h[0] -= sub0, h[top_index] = top
+template <class F>
+__global__ void k_h_fix(uint4* __restrict__ h, u64 top_index, FeArg sub0, FeArg top) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        fe_store(h, fe_sub<F>(fe_load(h), fe_from_arg(sub0)));
+        fe_store(h + 2 * top_index, fe_from_arg(top));
     }
 }
 

@@ -188,6 +188,11 @@ class R1CS:
         check(self.ctx.lib.acx_qap_h(self._h, _ptr(w), _ptr(dl), _ptr(out), C.byref(hlen), C.byref(ok)))
         return (out[: hlen.value] if ok.value else None), bool(ok.value)
 
+    def qap_h_dev(self, d_witness: int, d_h: int, d_result: int, delta: Optional[Sequence[int]] = None) -> None:
+        """verificationWitnessZk on device pointers (asynchronous): d_h gets N+1 dev elements."""
+        dl = ints_to_fr(list(delta)) if delta is not None else None
+        check(self.ctx.lib.acx_qap_h_dev(self._h, d_witness, _ptr(dl), d_h, d_result))
+
     def qap_columns(self, matrix: int, wire_begin: int, wire_count: int) -> Tuple[np.ndarray, np.ndarray]:
         N = 1 << self.log_n
         out = np.zeros((wire_count, N, 4), dtype=np.uint64)

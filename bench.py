@@ -66,31 +66,103 @@ def cpu_baseline(sample, field="bn254", budget_s=12.0):
                       f"(oracle/acx_oracle.c, {threads} pthreads, {dt:.1f} s)"}
 
 
-def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=50, prewarm=0.25):
-    """Secondary metric: one 2^20-point inverse NTT (= FFT.interpolate of one QAP column)."""
-    n = 1 << log_n
-    x = to_dev(ctx, synth.random_fr(n, 5, 1, field))
-    t_pre = time.perf_counter()                 # same clock-ramp pre-run as the main loop
+def _timed(stream, fn, reps, prewarm):
+    """Average us per call of fn over `reps` back-to-back calls (HIP events on libacx's stream), after the
+    clock-ramp pre-run."""
+    t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < prewarm:
-        for _ in range(16):
-            ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=True)
-        ctx.sync()
+        for _ in range(8):
+            fn()
+        stream.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stream.synchronize()
     e0.record(stream)
     for _ in range(reps):
-        ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=True)
+        fn()
     e1.record(stream)
     e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    ops = 1.5 * n * log_n + n
-    passes = 1 if log_n <= 8 else (log_n + 7) // 8
-    alg = 64 * passes * n          # one read + one write of every element per pass (DESIGN.md section 4)
-    return {"workload": f"inverse NTT N=2^{log_n} ({field} Fr), acx::k_ntt_tile x {passes} passes", "us": us,
-            "field_ops_per_s": ops / us * 1e6,
-            "roofline": {"bound": "hbm", "achieved": alg / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / us * 1e-3 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
-                         "note": "VALU-bound in practice: ~12.5 Montgomery products per element (profiles/r01_ntt_ablation.txt)"}}
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def _from_dev(ctx, t, count):
+    out = torch.empty_like(t)
+    ctx.dev_to_canonical(count, t.data_ptr(), out.data_ptr())
+    ctx.sync()
+    return out.cpu().numpy().view(np.uint64).reshape(-1, 4)[:count]
+
+
+def _hbm(alg_bytes, us, **extra):
+    d = {"bound": "hbm", "achieved": alg_bytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": alg_bytes / us * 1e-3 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes}
+    d.update(extra)
+    return d
+
+
+def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=40, prewarm=0.25, batch=64):
+    """Secondary metrics of configs[2]: one 2^20-point transform (= FFT.interpolate of one QAP
+    column) and a batch of 64 of them.  Parity gate first: the inverse transform of a fixed random vector is
+    compared with the C oracle's, element by element.  The timed loop alternates inverse and forward on that
+    vector, so every launch works on the same data (inverse then forward is the identity)."""
+    from oracle.c_oracle import COracle
+    orc = COracle(field)
+    n = 1 << log_n
+    x_host = synth.random_fr(n, 5, 1, field)
+    x = to_dev(ctx, x_host)
+    ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=True)
+    parity = bool(np.array_equal(_from_dev(ctx, x, n), orc.ntt(x_host, log_n, inverse=True, nthreads=os.cpu_count() or 1)))
+    ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=False)
+    parity = parity and bool(np.array_equal(_from_dev(ctx, x, n), x_host))
+    flip = [False]
+
+    def one():
+        flip[0] = not flip[0]
+        ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=flip[0])
+
+    us = _timed(stream, one, reps, prewarm)
+    ops = 1.5 * n * log_n + n / 2          # butterflies * 3, + the 1/N scaling of the inverse half of the launches
+    xb = to_dev(ctx, synth.random_fr(n * batch, 6, 1, field))
+    flipb = [False]
+
+    def many():
+        flipb[0] = not flipb[0]
+        ctx.ntt_dev(xb.data_ptr(), log_n, batch, inverse=flipb[0])
+
+    us_b = _timed(stream, many, 6, prewarm) / batch
+    alg = 128 * n      # SURVEY.md 8(d): two reads + two writes of every 32-byte element (two-pass four-step)
+    note = ("VALU-bound: ~10 Montgomery products (171 v_mad_u64_u32 each) per element; the HBM fraction is what "
+            "SURVEY.md 8(d) asks to be quoted, the VALU issue model is in profiles/r02_ntt_*.txt")
+    return {"workload": f"NTT N=2^{log_n} ({field} Fr), alternating inverse/forward on a fixed vector, acx::k_ntt_r4",
+            "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6,
+            "roofline": _hbm(alg, us, note=note),
+            "batch": {"transforms": batch, "us_per_transform": us_b, "field_ops_per_s": ops / us_b * 1e6,
+                      "roofline": _hbm(alg, us_b)}}
+
+
+def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
+    """configs[2]'s third C3 metric: the h(x) pipeline of verificationWitness (src/QAP.hs:309-327) on a
+    2^20-constraint mulgraph system, device resident (witness in, N+1 coefficients out): residual dots,
+    3 iNTT, 3 coset NTT, pointwise, coset iNTT.  Parity gate: every coefficient against the C oracle."""
+    from oracle.c_oracle import COracle
+    orc = COracle(field)
+    n = 1 << log_n
+    s = synth.mulgraph(n, seed=0xAC3, field=field)
+    mats, w = s.rows(), s.witness()
+    r = s.circuit.to_r1cs(ctx)
+    dw = to_dev(ctx, w)
+    dh = torch.zeros((n + 1, 4), dtype=torch.int64, device="cuda")
+    res = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    r.qap_h_dev(dw.data_ptr(), dh.data_ptr(), res.data_ptr())
+    ctx.sync()
+    got = _from_dev(ctx, dh, n + 1)
+    want, ok = orc.qap_h(n, r.m, log_n, *mats, w, nthreads=os.cpu_count() or 1)
+    parity = bool(ok and int(res[0]) == 0 and np.array_equal(got, want))
+    us = _timed(stream, lambda: r.qap_h_dev(dw.data_ptr(), dh.data_ptr(), res.data_ptr()), reps, prewarm)
+    b_r1cs, nnz, _ = algorithmic_bytes(mats, n)
+    alg = 7 * 128 * n + (b_r1cs + 3 * 32 * n) + 5 * 32 * n     # SURVEY.md 8(d): 7 NTTs + residual-style dots (written) + pointwise
+    ops = 7 * (1.5 * n * log_n) + 4 * n + nnz + n               # butterflies, scalings, dot-product MACs, pointwise
+    return {"workload": f"verificationWitness h(x), 2^{log_n}-constraint mulgraph ({field} Fr), device resident: residual dots + 7 NTTs + pointwise",
+            "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6, "roofline": _hbm(alg, us)}
 
 
 def main():
@@ -107,6 +179,7 @@ def main():
                     help="collective backend; gloo (with ACX_BENCH_ONE_DEVICE=1: every rank on cuda:0) lets the "
                          "multi-rank control flow be tested on a 1-GPU box")
     ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed launches before the warmup steps (clock ramp)")
+    ap.add_argument("--sustain", type=float, default=0.5, help="seconds of extra K-step blocks for the median/min per-step figures")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     a = ap.parse_args()
@@ -216,6 +289,25 @@ def main():
         if use_dist:
             dist.barrier()
     kernel_us = e0.elapsed_time(e1) * 1e3 / a.steps
+    # Sustained figure (SURVEY.md 8d "median and min reported"): blocks of K steps, each bracketed by HIP events, for
+    # at least --sustain seconds.  `value` stays the wall-clock of the exactly-K-step region above; these are
+    # reported beside it so that a DVFS hiccup in a few-millisecond region is visible.
+    block_us = []
+    if not use_dist and a.sustain > 0:
+        with torch.cuda.stream(stream):
+            t_s = time.perf_counter()
+            while time.perf_counter() - t_s < a.sustain:
+                evs = []
+                for _ in range(16):
+                    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    b0.record(stream)
+                    for i in range(a.steps):
+                        step(i)
+                    b1.record(stream)
+                    evs.append((b0, b1))
+                stream.synchronize()
+                block_us += [x.elapsed_time(y) * 1e3 / a.steps for x, y in evs]
+        assert int(results[:, 0].abs().sum()) == 0
     assert int(results[:, 0].abs().sum()) == 0, "a satisfying witness was rejected"     # parity gate of the timed config
 
     # negative control outside the timed region: one flipped witness limb must be caught.  A full
@@ -266,6 +358,12 @@ def main():
                          "kernel": "acx::k_r1cs_sell", "kernel_us": kernel_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if block_us:
+            bs = sorted(block_us)
+            out["sustained"] = {"blocks": len(bs), "steps_per_block": a.steps, "seconds": sum(bs) * a.steps * 1e-6,
+                                "us_per_step_median": bs[len(bs) // 2], "us_per_step_min": bs[0], "us_per_step_max": bs[-1],
+                                "frac_median": bytes_per_launch / bs[len(bs) // 2] * 1e-3 / HBM_PEAK_GBS,
+                                "note": "kernel times at the sustained clock (0.25 s untimed pre-run before the timed region)"}
         try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["acx::k_r1cs_sell"]
             if tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
@@ -275,6 +373,7 @@ def main():
             pass
         if world == 1 and not a.no_ntt:
             out["ntt"] = bench_ntt(ctx, stream, a.field, prewarm=a.prewarm)
+            out["qap_h"] = bench_qap_h(ctx, stream, a.field, prewarm=a.prewarm)
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(sample, a.field)
         print(json.dumps(out))

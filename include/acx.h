@@ -237,6 +237,10 @@ int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset,
                         void* d_residuals, void* d_dots);
 int acx_ntt_dev(acx_ctx* ctx, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift,
                 void* d_data);
+/* `verificationWitnessZk` (src/QAP.hs:300-327) on device-resident data: d_witness m dev elements; d_h receives
+ * N+1 dev elements = the quotient's coefficients low to high, zero beyond its degree (not stripped);
+ * d_result {n_bad, first_bad} accumulates like acx_r1cs_verify_dev (n_bad != 0 <=> `Nothing`).  delta may be NULL. */
+int acx_qap_h_dev(acx_r1cs* r, const void* d_witness, const acx_fr* delta, void* d_h, uint64_t* d_result);
 
 /* Twiddle step of a four-step / distributed NTT of length 2^log_n = R*C: the rows x cols tile at
  * (row0, col0) of the R x C matrix is multiplied elementwise by omega_N^((row0+r)*(col0+c))
