@@ -63,13 +63,17 @@ struct acx_ctx {
     std::map<std::tuple<uint32_t, uint64_t, int, uint32_t>, uint4*> tw_scaled;   // (log_m, count, inverse, log_n of folded 1/N)
     std::map<std::pair<uint32_t, int>, uint4*> tw_limbs;  // (log_m, inverse) -> omega_M^j, j < M/2, limb form (k_ntt_r4)
     NttCfg ntt;
-    int coset_scaled = 0;                                  // coset_lo carries the 1/N of an inverse transform
     uint4* ntt_scratch = nullptr;                          // ping-pong buffer of the multi-pass NTT
     size_t ntt_scratch_bytes = 0;
-    uint4* coset_lo = nullptr;                             // g^j (j < 1024), g^(1024 j): last shift used
-    uint4* coset_hi = nullptr;
-    H256 coset_base{{0, 0, 0, 0}};
-    uint32_t coset_log_n = 0;
+    struct CosetTables {                                   // g^j (j < 1024), g^(1024 j) for one (g, log_n, scaled)
+        uint4 *lo = nullptr, *hi = nullptr;
+        H256 base{{0, 0, 0, 0}};
+        uint32_t log_n = 0;
+        int scaled = 0;
+        uint64_t stamp = 0;
+    };
+    CosetTables cosets[8];
+    uint64_t coset_clock = 0;
     unsigned long long* d_result = nullptr;                // {n_bad, first_bad}
     uint32_t* d_err = nullptr;
     int n_cu = 256;
@@ -277,32 +281,40 @@ int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, ui
     return ACX_OK;
 }
 
-// g^j (j < 1024) and g^(1024 j) (j < N/1024) for the coset factor; the last (g, log_n) is kept.
+// g^j (j < 1024) and g^(1024 j) (j < N/1024) for the coset factor.  A small cache: the h(x) pipeline alternates
+// between g (forward) and 1/g with 1/N folded in (inverse) on every call.
 // scaled: the low table carries the factor 1/2^log_n (closing multiplication of an inverse coset transform).
 int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scaled, uint4** lo, uint4** hi) {
-    const uint64_t hi_count = log_n > 10 ? (1ull << (log_n - 10)) : 0;
-    if (!(c->coset_lo && c->coset_base == base_mont && c->coset_log_n == log_n && c->coset_scaled == scaled)) {
-        HIP_TRY(hipStreamSynchronize(c->stream));   // previous users of the old tables are done
-        if (c->coset_lo) (void)hipFree(c->coset_lo);
-        if (c->coset_hi) (void)hipFree(c->coset_hi);
-        c->coset_lo = c->coset_hi = nullptr;
-        HIP_TRY(hipMalloc((void**)&c->coset_lo, 1024 * 32));
-        const H256 first = scaled ? c->hf.inv(c->hf.from_u64(1ull << log_n)) : c->hf.one();
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(4), dim3(kBlock), 0, c->stream, c->coset_lo,
-                                             (u64)1024, dev_arg(c->hf, base_mont), dev_arg(c->hf, first)));
-        if (hi_count) {
-            HIP_TRY(hipMalloc((void**)&c->coset_hi, hi_count * 32));
-            const H256 b1024 = c->hf.pow_u64(base_mont, 1024);
-            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, hi_count)), dim3(kBlock), 0, c->stream,
-                                                 c->coset_hi, hi_count, dev_arg(c->hf, b1024)));
+    for (auto& e : c->cosets)
+        if (e.lo && e.base == base_mont && e.log_n == log_n && e.scaled == scaled) {
+            e.stamp = ++c->coset_clock;
+            *lo = e.lo; *hi = e.hi;
+            return ACX_OK;
         }
-        HIP_TRY(hipGetLastError());
-        c->coset_base = base_mont;
-        c->coset_log_n = log_n;
-        c->coset_scaled = scaled;
+    // evict the least recently used slot
+    acx_ctx::CosetTables* slot = &c->cosets[0];
+    for (auto& e : c->cosets) if (!e.lo || e.stamp < slot->stamp) { slot = &e; if (!e.lo) break; }
+    if (slot->lo) {
+        HIP_TRY(hipStreamSynchronize(c->stream));   // previous users of the old tables are done
+        (void)hipFree(slot->lo);
+        if (slot->hi) (void)hipFree(slot->hi);
+        slot->lo = slot->hi = nullptr;
     }
-    *lo = c->coset_lo;
-    *hi = c->coset_hi;
+    const uint64_t hi_count = log_n > 10 ? (1ull << (log_n - 10)) : 0;
+    HIP_TRY(hipMalloc((void**)&slot->lo, 1024 * 32));
+    const H256 first = scaled ? c->hf.inv(c->hf.from_u64(1ull << log_n)) : c->hf.one();
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(4), dim3(kBlock), 0, c->stream, slot->lo,
+                                         (u64)1024, dev_arg(c->hf, base_mont), dev_arg(c->hf, first)));
+    if (hi_count) {
+        HIP_TRY(hipMalloc((void**)&slot->hi, hi_count * 32));
+        const H256 b1024 = c->hf.pow_u64(base_mont, 1024);
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, hi_count)), dim3(kBlock), 0, c->stream,
+                                             slot->hi, hi_count, dev_arg(c->hf, b1024)));
+    }
+    HIP_TRY(hipGetLastError());
+    slot->base = base_mont; slot->log_n = log_n; slot->scaled = scaled; slot->stamp = ++c->coset_clock;
+    *lo = slot->lo;
+    *hi = slot->hi;
     return ACX_OK;
 }
 
@@ -511,6 +523,8 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
             Q.scale_mode = (inverse && shift_mont) ? 2 : 1;
             if (r4 && Q.scale_mode == 1 && (!inverse || fold_scale)) Q.scale_mode = 0;   // nothing left to multiply by
         }
+        Q.stride_t_in_hi = Q.stride_t_in;      // single stride in the transform direction (split = 0)
+        Q.stride_t_out_hi = Q.stride_t_out;
         const uint64_t tiles = batch * N / (S * T);
         if (tiles > 0x7fffffffull) return fail(ACX_ERR_TOO_LARGE, "NTT grid too large");
         if (r4) {
@@ -524,6 +538,107 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
             DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_tile<F>), dim3((unsigned)tiles), dim3(kBlock), 0, c->stream, Q));
         }
     }
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+// ---- local steps of the distributed four-step transform ------------------------------
+// N = R*C, index split i = i1*C + i2, k = k1 + k2*R; W ranks; rank g owns the i2 block g (i side) and the k1
+// block g (k side).  Local layouts (N/W dev elements each):
+//   COLS  [i2l][i1]        x[i1*C + g*C/W + i2l]                        (i side: every local column contiguous)
+//   ROWS  [kl][k2]         X[(g*R/W + kl) + k2*R]                       (k side: every local row contiguous)
+//   XCHG  [peer][kl][i2l]  W contiguous chunks of (R/W)*(C/W) elements: what ONE all-to-all moves
+// forward:  step 0  COLS -> XCHG  (length-R transforms over i1, times w_N^(i2*k1), coset factor s^i on load)
+//           step 1  XCHG -> ROWS  (length-C transforms over i2)
+// inverse:  step 0  ROWS -> XCHG  (length-C inverse transforms over k2, times w_N^-(i2*k1) / N)
+//           step 1  XCHG -> COLS  (length-R inverse transforms over k1, coset factor s^-i at the end)
+// Each step is ONE launch of k_ntt_r4: the transposes are strides of the pass descriptor, the twiddle is the
+// kernel's closing multiplication from tables -- no separate twiddle kernel, no permute copies.
+int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
+                         const H256* shift_mont, const uint4* in, uint4* out) {
+    const HostField& hf = c->hf;
+    const NttCfg& cfg = c->ntt;
+    if ((int)log_n > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
+    if (log_r >= log_n) return fail(ACX_ERR_INVALID_ARG, "log_r must be below log_n");
+    const uint32_t log_c = log_n - log_r;
+    if (log_r < 5 || log_r > 12 || log_c < 5 || log_c > 12)
+        return fail(ACX_ERR_UNSUPPORTED, "distributed NTT steps need 5 <= log_r, log_n - log_r <= 12");
+    if (world == 0 || (world & (world - 1)) || rank >= world) return fail(ACX_ERR_INVALID_ARG, "world must be a power of two, rank < world");
+    const uint64_t N = 1ull << log_n, R = 1ull << log_r, C = 1ull << log_c;
+    if (R % world || C % world) return fail(ACX_ERR_INVALID_ARG, "world must divide both factors of N");
+    const uint64_t rw = R / world, cw = C / world;
+    if (in == out) return fail(ACX_ERR_INVALID_ARG, "distributed NTT steps are out of place");
+    // which digit this launch transforms, and over how many local columns
+    const bool over_r = (step == 0) != (inverse != 0);      // forward step 0 and inverse step 1 transform the R digit
+    const uint32_t ls = over_r ? log_r : log_c;
+    const uint64_t S = 1ull << ls, cols = over_r ? cw : rw;
+    const uint32_t odd = ls & 1u;
+    const int lp = (int)(ls + odd);
+    uint64_t t_want = std::min<uint64_t>(std::max<uint64_t>(1ull << cfg.tile_log, S << odd) / S, cols);
+    while (t_want > (1ull << odd) && cols / t_want < 4ull * (uint64_t)c->n_cu) t_want >>= 1;
+    if (t_want < (1ull << odd)) return fail(ACX_ERR_UNSUPPORTED, "distributed NTT step: odd digit needs two local columns");
+    const int lgrp = r4_pick_lg(lp, (int)ilog2(t_want) - (int)odd);
+    if (lgrp < 0) return fail(ACX_ERR_UNSUPPORTED, "distributed NTT step: no kernel instance");
+    const uint64_t T = 1ull << (lgrp + odd);
+    NttPass Q;
+    std::memset(&Q, 0, sizeof(Q));
+    Q.src = in; Q.dst = out;
+    Q.log_s = ls; Q.log_t = ilog2(T);
+    { uint4* st = nullptr; ACX_TRY(get_limb_table(c, ls, inverse, &st)); Q.sub_tw = st; }
+    Q.idx_mask = N - 1;
+    const uint64_t chunk = rw * cw;
+    const bool twiddle_here = step == 0;
+    if (!inverse && step == 0) {            // COLS -> XCHG
+        Q.stride_t_in = 1; Q.stride_t_in_hi = 1; Q.stride_c_in = R;
+        Q.stride_t_out = cw; Q.stride_t_out_hi = cw; Q.stride_c_out = 1;
+        Q.outer[0] = NttOuter{(u32)(cols / T), 0, T * R, T, 0, T};
+        Q.t_kw = 1; Q.c_iw = 1; Q.i_base = (uint64_t)rank * cw;          // K = k1, I = i2
+    } else if (!inverse) {                  // XCHG -> ROWS
+        Q.split_in = ilog2(cw); Q.stride_t_in = 1; Q.stride_t_in_hi = chunk; Q.stride_c_in = cw;
+        Q.stride_t_out = 1; Q.stride_t_out_hi = 1; Q.stride_c_out = C;
+        Q.outer[0] = NttOuter{(u32)(cols / T), 0, T * cw, T * C, 0, 0};
+    } else if (step == 0) {                 // ROWS -> XCHG
+        Q.stride_t_in = 1; Q.stride_t_in_hi = 1; Q.stride_c_in = C;
+        Q.split_out = ilog2(cw); Q.stride_t_out = 1; Q.stride_t_out_hi = chunk; Q.stride_c_out = cw;
+        Q.outer[0] = NttOuter{(u32)(cols / T), 0, T * C, T * cw, 0, T};
+        Q.t_kw = 1; Q.c_iw = 1; Q.i_base = (uint64_t)rank * rw;          // "K" = i2 (the digit), "I" = k1 (the column)
+    } else {                                // XCHG -> COLS
+        Q.stride_t_in = cw; Q.stride_t_in_hi = cw; Q.stride_c_in = 1;
+        Q.stride_t_out = 1; Q.stride_t_out_hi = 1; Q.stride_c_out = R;
+        Q.outer[0] = NttOuter{(u32)(cols / T), 0, T, T * R, 0, T};
+        Q.c_iw = 1; Q.i_base = (uint64_t)rank * cw;                       // I = i2 (coset exponent only)
+    }
+    Q.n_outer = Q.outer[0].count > 1 ? 1 : 0;
+    if (twiddle_here) {
+        const uint32_t fold = inverse ? log_n : 0;                         // 1/N of the inverse transform rides on the twiddles
+        if (log_n <= std::max<uint32_t>(cfg.direct_tw, 16)) {
+            uint4* tw = nullptr;
+            ACX_TRY(get_scaled_table(c, log_n, N, inverse, fold, &tw));
+            Q.tw_mode = 1; Q.tw_lo = tw; Q.tw_shift = 0;
+        } else {
+            uint4 *lo = nullptr, *hi = nullptr;
+            ACX_TRY(get_scaled_table(c, log_n, 1024, inverse, fold, &lo));
+            ACX_TRY(get_pow_table(c, log_n - 10, inverse, &hi));
+            Q.tw_mode = 2; Q.tw_lo = lo; Q.tw_hi = hi; Q.tw_mask = N - 1;
+        }
+    }
+    Q.scale = dev_arg(hf, hf.one());
+    if (shift_mont && ((!inverse && step == 0) || (inverse && step == 1))) {
+        // coset factor s^i (forward, on load) / s^-i (inverse, closing), i = i1*C + i2: digit i1, column i2
+        const H256 base = inverse ? hf.inv(*shift_mont) : *shift_mont;
+        uint4 *lo = nullptr, *hi = nullptr;
+        ACX_TRY(get_coset_tables(c, base, log_n, 0, &lo, &hi));
+        Q.sc_lo = lo; Q.sc_hi = hi;
+        Q.e_mode = 1; Q.e_t = C; Q.e_c = 1;
+        if (inverse) Q.scale_mode = 2; else Q.scale_on_load = 1;
+    }
+    const uint64_t tiles = cols / T;
+    bool ok = false;
+    DISPATCH_FIELD(c, {
+        ok = cfg.xchg == 1 ? launch_r4<F, kXchgDpp>(lp, lgrp, (unsigned)tiles, c->stream, Q)
+                           : launch_r4<F, kXchgLds>(lp, lgrp, (unsigned)tiles, c->stream, Q);
+    });
+    if (!ok) return fail(ACX_ERR_UNSUPPORTED, "distributed NTT step: kernel instance missing");
     HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
@@ -873,8 +988,7 @@ void acx_ctx_destroy(acx_ctx* c) {
     for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
     for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
     if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
-    if (c->coset_lo) (void)hipFree(c->coset_lo);
-    if (c->coset_hi) (void)hipFree(c->coset_hi);
+    for (auto& e : c->cosets) { if (e.lo) (void)hipFree(e.lo); if (e.hi) (void)hipFree(e.hi); }
     if (c->d_result) (void)hipFree(c->d_result);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1401,19 +1515,35 @@ int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset,
                            (uint4*)d_residuals, (uint4*)d_dots, 1ull << r->log_n);
 }
 
-int acx_ntt_twiddle_dev(acx_ctx* c, uint32_t log_n, int inverse, uint64_t rows, uint64_t cols, uint64_t row0,
-                        uint64_t col0, void* d_data) {
-    if (!c || !d_data) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
-    if (rows == 0 || cols == 0) return ACX_OK;
+int acx_qap_pointwise_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_fr* shift, const void* d_a, const void* d_b,
+                          const void* d_c, void* d_out) {
+    if (!c || !shift || !d_a || !d_b || !d_c || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (count == 0) return ACX_OK;
+    const HostField& hf = c->hf;
+    H256 g;
+    ACX_TRY(read_h256(shift, hf, g));
+    const H256 z = hf.sub(hf.pow_u64(g, 1ull << log_n), hf.one());
+    if (z.is_zero()) return fail(ACX_ERR_INVALID_ARG, "shift^N = 1: the coset meets the evaluation domain");
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    H256 w = c->hf.root_of_unity((int)log_n);
-    if (inverse) w = c->hf.inv(w);
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_twiddle_tile<F>), dim3(grid_for(c, rows * cols)), dim3(kBlock), 0, c->stream,
-                                         (uint4*)d_data, rows, cols, row0, col0, dev_arg(c->hf, w)));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, (const uint4*)d_a,
+                                         (const uint4*)d_b, (const uint4*)d_c, (uint4*)d_out, count, dev_arg(hf, hf.inv(z))));
     HIP_TRY(hipGetLastError());
     return ACX_OK;
+}
+
+int acx_ntt_dist_step_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
+                          const acx_fr* shift, const void* d_in, void* d_out) {
+    if (!c || !d_in || !d_out || (step != 0 && step != 1)) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    H256 sh;
+    if (shift) {
+        ACX_TRY(read_h256(shift, c->hf, sh));
+        if (sh.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift must be nonzero");
+    }
+    return ntt_dist_step_locked(c, log_n, log_r, world, rank, inverse, step, shift ? &sh : nullptr, (const uint4*)d_in,
+                                (uint4*)d_out);
 }
 
 // ---------------------------------------------------------------------------------- naive-roots path

@@ -369,6 +369,15 @@ struct NttPass {
     u64 t_kw;              // K contribution of the output digit k_p
     u64 c_kw, c_iw;        // K / I contribution of the column index
     u64 idx_mask;          // element index within its transform = offset & idx_mask (coset exponent)
+    // --- used by k_ntt_r4 only (local steps of the distributed four-step transform, acx_ntt_dist_step_dev) ---
+    // transform-direction offset of digit d = (d & (2^split - 1)) * stride_t + (d >> split) * stride_t_hi;
+    // the planner's default split = 0, stride_t_hi = stride_t is the plain single stride.
+    u32 split_in, split_out;
+    u64 stride_t_in_hi, stride_t_out_hi;
+    u64 k_base, i_base;    // constants added to the twiddle factors K and I (this rank's block offset)
+    u32 e_mode;            // coset exponent: 0 = offset & idx_mask, 1 = e_base + digit * e_t + I * e_c (I = the column's global index)
+    u32 pad2;
+    u64 e_base, e_t, e_c;
     NttOuter outer[kMaxOuter];
     FeArg scale;
 };
@@ -452,19 +461,6 @@ __global__ __launch_bounds__(kBlock) void k_ntt_tile(NttPass P) {
             f = scale;
         }
         fe_store(P.dst + 2 * off, fe_mul<F>(x, f));
-    }
-}
-
-// Four-step twiddle: data is a rows x cols tile (row-major) of the R x C matrix of a length-N = R*C
-// transform; element (r, c) *= omega^((row0 + r) * (col0 + c)).  omega = omega_N (or its inverse).
-template <class F>
-__global__ __launch_bounds__(kBlock) void k_twiddle_tile(uint4* __restrict__ data, u64 rows, u64 cols, u64 row0,
-                                                        u64 col0, FeArg omega_arg) {
-    const Fe omega = fe_from_arg(omega_arg);
-    for (u64 t = (u64)blockIdx.x * kBlock + threadIdx.x; t < rows * cols; t += (u64)gridDim.x * kBlock) {
-        const u64 r = t / cols, c = t - r * cols;
-        const Fe tw = fe_pow<F>(omega, (row0 + r) * (col0 + c));
-        fe_store(data + 2 * t, fe_mul<F>(fe_load(data + 2 * t), tw));
     }
 }
 

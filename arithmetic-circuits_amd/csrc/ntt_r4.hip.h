@@ -170,12 +170,13 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
     Fe x[4];
     {
         const u32 col = (g << odd) | (u & odd);
-        const u64 cbase = base_in + (u64)col * P.stride_c_in + (u64)(u >> odd) * P.stride_t_in;
-        const u64 estride = (u64)P.stride_t_in << (ls - 2);
+        const u64 cbase = base_in + (u64)col * P.stride_c_in;
+        const u32 dlow = u >> odd, smask = (1u << P.split_in) - 1u;
         uint4 raw[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint4* p = P.src + 2 * (cbase + (u64)rev2(e) * estride);
+            const u32 d = (rev2(e) << (ls - 2)) | dlow;
+            const uint4* p = P.src + 2 * (cbase + (u64)(d & smask) * P.stride_t_in + (u64)(d >> P.split_in) * P.stride_t_in_hi);
             raw[2 * e] = gload(p);
             raw[2 * e + 1] = gload(p + 1);
         }
@@ -188,8 +189,10 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
         if (P.scale_on_load) {               // coset pre-multiplication of a forward transform
 #pragma unroll 1
             for (u32 e = 0; e < 4; ++e) {
-                const u64 off = cbase + (u64)rev2(e) * estride;
-                const Fe y = fe_mul<F>(x[0], two_level_pow<F>(P.sc_lo, P.sc_hi, off & P.idx_mask));
+                const u32 d = (rev2(e) << (ls - 2)) | dlow;
+                const u64 off = cbase + (u64)(d & smask) * P.stride_t_in + (u64)(d >> P.split_in) * P.stride_t_in_hi;
+                const u64 ex = P.e_mode ? (P.e_base + (u64)d * P.e_t + (P.i_base + I0 + (u64)col * P.c_iw) * P.e_c) : (off & P.idx_mask);
+                const Fe y = fe_mul<F>(x[0], two_level_pow<F>(P.sc_lo, P.sc_hi, ex));
                 x[0] = x[1]; x[1] = x[2]; x[2] = x[3]; x[3] = y;
             }
         }
@@ -258,16 +261,18 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
         x[0] = x[1]; x[1] = x[2]; x[2] = x[3];
         const u32 col = odd ? ((g << 1) | (e >> 1)) : g;
         const u32 kd = odd ? (((e & 1u) << LU) | v) : ((e << LU) | v);
-        const u64 off = base_out + (u64)kd * P.stride_t_out + (u64)col * P.stride_c_out;
+        const u64 off = base_out + (u64)(kd & ((1u << P.split_out) - 1u)) * P.stride_t_out +
+                        (u64)(kd >> P.split_out) * P.stride_t_out_hi + (u64)col * P.stride_c_out;
         Fe f = scale;
         bool mul = true;
         if (P.tw_mode == 1) {
-            const u64 K = K0 + (u64)kd * P.t_kw + (u64)col * P.c_kw, I = I0 + (u64)col * P.c_iw;
+            const u64 K = P.k_base + K0 + (u64)kd * P.t_kw + (u64)col * P.c_kw, I = P.i_base + I0 + (u64)col * P.c_iw;
             f = fe_load(P.tw_lo + 2 * ((I * K) >> P.tw_shift));
         } else if (P.tw_mode == 2 || P.scale_mode == 2) {
-            const u64 K = K0 + (u64)kd * P.t_kw + (u64)col * P.c_kw, I = I0 + (u64)col * P.c_iw;
+            const u64 K = P.k_base + K0 + (u64)kd * P.t_kw + (u64)col * P.c_kw, I = P.i_base + I0 + (u64)col * P.c_iw;
             const bool tw = P.tw_mode == 2;
-            f = two_level_pow<F>(tw ? P.tw_lo : P.sc_lo, tw ? P.tw_hi : P.sc_hi, tw ? ((I * K) & P.tw_mask) : (off & P.idx_mask));
+            const u64 ex = P.e_mode ? (P.e_base + (u64)kd * P.e_t + I * P.e_c) : (off & P.idx_mask);
+            f = two_level_pow<F>(tw ? P.tw_lo : P.sc_lo, tw ? P.tw_hi : P.sc_hi, tw ? ((I * K) & P.tw_mask) : ex);
         } else if (P.scale_mode == 0) {
             mul = false;
         }

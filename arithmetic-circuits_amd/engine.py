@@ -103,9 +103,15 @@ class Context:
         check(self.lib.acx_ntt_dev(self._h, log_n, batch, int(inverse), _ptr(sh), d_data))
 
 
-    def ntt_twiddle_dev(self, d_data: int, log_n: int, rows: int, cols: int, row0: int = 0, col0: int = 0,
-                        inverse: bool = False) -> None:
-        check(self.lib.acx_ntt_twiddle_dev(self._h, log_n, int(inverse), rows, cols, row0, col0, d_data))
+    def qap_pointwise_dev(self, d_a: int, d_b: int, d_c: int, d_out: int, count: int, log_n: int, shift: int) -> None:
+        sh = ints_to_fr([shift])
+        check(self.lib.acx_qap_pointwise_dev(self._h, log_n, count, _ptr(sh), d_a, d_b, d_c, d_out))
+
+    def ntt_dist_step_dev(self, d_in: int, d_out: int, log_n: int, log_r: int, world: int, rank: int, inverse: bool, step: int,
+                          shift: Optional[int] = None) -> None:
+        """One local step of the distributed four-step NTT (include/acx.h: COLS / ROWS / XCHG layouts)."""
+        sh = ints_to_fr([shift]) if shift is not None else None
+        check(self.lib.acx_ntt_dist_step_dev(self._h, log_n, log_r, world, rank, int(inverse), step, _ptr(sh), d_in, d_out))
 
 
 class R1CS:

@@ -3,30 +3,44 @@
 The reference is single-threaded Haskell with nothing distributed; the sharding
 below follows from the maths of the path:
 
-  * R1CS check (`verifyAssignment`, src/QAP.hs:276-282): constraint rows are independent.  Rank r
-    holds a contiguous, nnz-balanced slab of rows as its own device-resident system, the witness
-    is replicated, and the verdict is ONE all-reduce of the violated-row count (plus a MIN
-    all-reduce of the first violated row when the caller asks for it).
+  * R1CS check (`verifyAssignment`, src/QAP.hs:276-282): constraint rows are independent.  Every
+    rank holds its own rows as a device-resident system (marshalled locally: no rank ever builds
+    the whole matrix), the witness is replicated, and the verdict is ONE all-reduce (SUM of the
+    violated-row counts, the non-canonical-witness flag rides in the same message).  The smallest
+    violated row costs a second all-reduce (MIN) and is only computed on request.
   * Large NTT (`FFT.interpolate`, src/QAP.hs:521-523, at N = 2^24): four-step decomposition
-    N = R*C with ONE all-to-all transpose between the two local passes.
+    N = R*C with ONE all-to-all between the two local steps.  Each local step is one kernel
+    launch of libacx (`acx_ntt_dist_step_dev`): the transposes around the exchange are strides of
+    that launch and the w_N^(i2*k1) twiddle is its closing multiplication.
+  * h(x) (`verificationWitnessZk`, src/QAP.hs:309-327) over all GPUs: rows are owned
+    block-cyclically (rank g: rows r with (r mod R) in block g) so that the residual kernel writes
+    <A_i,w>, <B_i,w>, <C_i,w> straight into the layout the first inverse transform reads; seven
+    distributed transforms = seven all-to-alls, nothing else moves.
 
-The collectives live here, above the C ABI; libacx only ever sees one GPU.  `LocalOps` is the
-seam: the product uses `HipOps` (HIP kernels through libacx); the CPU test-suite injects an
-oracle-backed implementation to exercise the distributed logic with the gloo backend."""
+The collectives live here, above the C ABI; libacx only ever sees one GPU (a C host does the same
+with rcclCommInitRank / ncclAllToAll: INTEGRATION.md).  `LocalOps` is the seam: the product uses
+`HipOps` (HIP kernels through libacx); the CPU test-suite injects an oracle-backed implementation
+to exercise the distributed logic with the gloo backend."""
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine import Context, R1CS, fr_to_ints, ints_to_fr
+from .engine import Context, R1CS
 
 U64_MAX = (1 << 64) - 1
 
 
-# ------------------------------------------------------------------------------------ row sharding
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+# ------------------------------------------------------------------------------------ row ownership
 def shard_bounds(rowptrs: Sequence[np.ndarray], world: int) -> List[int]:
     """Split rows [0, n) into `world` contiguous slabs balanced by nnz of A+B+C (Split gates make
     257-row bursts of very uneven length, test/Test/Circuit/Arithmetic.hs:123).  Returns world+1
@@ -52,76 +66,177 @@ def slice_rows(mat, lo: int, hi: int):
     return (np.asarray(rowptr[lo:hi + 1], dtype=np.uint32) - np.uint32(e0)), col[e0:e1], val[e0:e1]
 
 
-class ShardedR1CS:
-    """A constraint system whose rows are sharded over the ranks of a process group."""
+def gather_rows(mat, rows: np.ndarray):
+    """CSR of the given rows (any order; indices >= n give empty rows) of a host CSR triple."""
+    rowptr, col, val = mat
+    rp = np.asarray(rowptr, dtype=np.int64)
+    n = rp.shape[0] - 1
+    rows = np.asarray(rows, dtype=np.int64)
+    live = rows < n
+    loc = np.where(live, rows, 0)
+    lens = np.where(live, rp[loc + 1] - rp[loc], 0)
+    new_rp = np.concatenate([[0], np.cumsum(lens)])
+    owner = np.repeat(np.arange(rows.shape[0], dtype=np.int64), lens)
+    src = rp[loc][owner] + (np.arange(int(new_rp[-1]), dtype=np.int64) - new_rp[:-1][owner])
+    return new_rp.astype(np.uint32), np.ascontiguousarray(col[src]), np.ascontiguousarray(val[src])
 
-    def __init__(self, mats, m: int, group=None, ctx: Optional[Context] = None, local_verify=None):
-        """mats: the full host CSR triple (every rank passes the same); each rank keeps its slab.
-        local_verify(mats_local, m, witness) -> (n_bad, first_bad_local) replaces the HIP path in
-        CPU tests; the product path requires `ctx` (a GPU context) and has no fallback."""
+
+def cyclic_rows(log_n: int, log_r: int, world: int, rank: int) -> np.ndarray:
+    """Global row numbers owned by `rank` under the block-cyclic ownership of SURVEY.md 8(e), in local
+    ROWS-layout order [kl][k2]: row = (rank*R/W + kl) + k2*R.  N/W entries (rows >= n are padding)."""
+    R, C = 1 << log_r, 1 << (log_n - log_r)
+    rw = R // world
+    kl = np.arange(rw, dtype=np.int64).reshape(-1, 1)
+    k2 = np.arange(C, dtype=np.int64).reshape(1, -1)
+    return (rank * rw + kl + k2 * R).reshape(-1)
+
+
+RowSource = Callable[[np.ndarray], Tuple[tuple, tuple, tuple]]
+
+
+class ShardedR1CS:
+    """A constraint system whose rows are sharded over the ranks of a process group.
+
+    Ownership: `rows` = this rank's global row numbers in local order (`from_slabs`: a contiguous
+    nnz-balanced slab; `from_cyclic`: the block-cyclic ownership the distributed h(x) pipeline needs).
+    Only those rows are marshalled and uploaded on this rank."""
+
+    def __init__(self, rows: np.ndarray, local_mats, n: int, m: int, group=None, ctx: Optional[Context] = None,
+                 local_verify=None, local_dots=None):
+        """local_verify(mats_local, m, witness, rows) -> (n_bad, smallest violated GLOBAL row) and local_dots(mats_local, m, witness) ->
+        (3*rows, 4) int64 tensor replace the HIP path in CPU tests; the product path requires `ctx` (a GPU
+        context) and has no fallback."""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.n = len(mats[0][0]) - 1
-        self.m = m
-        self.bounds = shard_bounds([mt[0] for mt in mats], self.world)
-        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
-        self.local_mats = [slice_rows(mt, self.lo, self.hi) for mt in mats]
+        self.world, self.rank = _world(group)
+        self.rows = np.asarray(rows, dtype=np.int64)
+        self.local_mats = local_mats
+        self.n, self.m = n, m
         self._local_verify = local_verify
+        self._local_dots = local_dots
         self.ctx = ctx
         self.r1cs = None
         if local_verify is None:
             if ctx is None:
                 raise RuntimeError("ShardedR1CS needs a GPU Context (libacx has no CPU fallback)")
-            self.r1cs = R1CS.load(ctx, self.hi - self.lo, m, *self.local_mats)
-            self._res = torch.zeros(2, dtype=torch.int64, device=f"cuda:{ctx.device}")
-            self._wbuf = None
-
-    def verify(self, witness: np.ndarray) -> Tuple[bool, int, int]:
-        """verifyAssignment over all shards: (ok, n_bad, first_bad) identical on every rank."""
-        if self._local_verify is not None:
-            n_bad, first_local = self._local_verify(self.local_mats, self.m, witness)
-            dev = "cpu"
-            cnt = torch.tensor([n_bad], dtype=torch.int64)
-            first = torch.tensor([first_local + self.lo if n_bad else (1 << 62)], dtype=torch.int64)
-        else:
-            ctx = self.ctx
+            self.r1cs = R1CS.load(ctx, self.rows.shape[0], m, *local_mats)
             dev = f"cuda:{ctx.device}"
-            w = torch.from_numpy(np.ascontiguousarray(witness, dtype=np.uint64).view(np.int64)).to(dev)
-            torch.cuda.synchronize()
-            ctx.dev_from_canonical(self.m, w.data_ptr(), w.data_ptr())
-            stream = torch.cuda.ExternalStream(ctx.stream)
-            with torch.cuda.stream(stream):
-                self._res.copy_(torch.tensor([0, -1], dtype=torch.int64), non_blocking=False)
-                self.r1cs.verify_dev(w.data_ptr(), self._res.data_ptr(), row_offset=self.lo)
-                cnt = self._res[:1].clone()
-                # first_bad is an unsigned 64-bit value with UINT64_MAX = none; map to signed order
-                first = torch.where(self._res[1:2] < 0, torch.full_like(self._res[1:2], 1 << 62), self._res[1:2])
-            stream.synchronize()
+            self._res = torch.zeros(2, dtype=torch.int64, device=dev)
+            self._flag = torch.zeros(2, dtype=torch.int32, device=dev)       # [0] = non-canonical witness
+            self._stream = torch.cuda.ExternalStream(ctx.stream)
+
+    # -- constructors ---------------------------------------------------------------------------
+    @classmethod
+    def from_slabs(cls, mats, m: int, **kw) -> "ShardedR1CS":
+        """Contiguous slabs balanced by nnz.  `mats` is the full host CSR triple (cheap for the sizes where a
+        single host can hold it; large jobs use `from_source`)."""
+        world, rank = _world(kw.get("group"))
+        n = len(mats[0][0]) - 1
+        bounds = shard_bounds([mt[0] for mt in mats], world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        self = cls(np.arange(lo, hi, dtype=np.int64), [slice_rows(mt, lo, hi) for mt in mats], n, m, **kw)
+        self.bounds = bounds
+        return self
+
+    @classmethod
+    def from_source(cls, source: RowSource, rows: np.ndarray, n: int, m: int, **kw) -> "ShardedR1CS":
+        """Rank-local construction: `source(rows)` returns the CSR triples of exactly these global rows."""
+        return cls(rows, list(source(rows)), n, m, **kw)
+
+    @classmethod
+    def from_cyclic(cls, source: RowSource, n: int, m: int, log_n: int, log_r: int, **kw) -> "ShardedR1CS":
+        world, rank = _world(kw.get("group"))
+        return cls.from_source(source, cyclic_rows(log_n, log_r, world, rank), n, m, **kw)
+
+    # -- verifyAssignment -------------------------------------------------------------------------
+    def to_device_witness(self, witness: np.ndarray) -> torch.Tensor:
+        """Upload + convert the (replicated) witness; canonicity is checked on the device like the single-GPU path
+        does (acx_r1cs_verify): the flag travels with the verdict's all-reduce."""
+        ctx = self.ctx
+        w = torch.from_numpy(np.ascontiguousarray(witness, dtype=np.uint64).view(np.int64)).to(f"cuda:{ctx.device}")
+        self._flag.zero_()
+        torch.cuda.synchronize()
+        ctx.dev_from_canonical(self.m, w.data_ptr(), w.data_ptr(), self._flag.data_ptr())
+        return w
+
+    def verify(self, witness: np.ndarray, want_first: bool = False) -> Tuple[bool, int, int]:
+        """verifyAssignment over all shards: (ok, n_bad, first_bad) identical on every rank.  ONE collective;
+        first_bad (smallest violated global row) costs a second one and is U64_MAX unless want_first."""
+        if self._local_verify is not None:
+            n_bad, first_global = self._local_verify(self.local_mats, self.m, witness, self.rows)
+            verdict = torch.tensor([n_bad, 0], dtype=torch.int64)
+            first = torch.tensor([first_global if n_bad else (1 << 62)], dtype=torch.int64)
+        else:
+            w = self.to_device_witness(witness)
+            verdict, first = self.verify_dev(w, want_first)
+        return self._reduce(verdict, first, want_first)
+
+    def verify_dev(self, w: torch.Tensor, want_first: bool = False, dots: Optional[torch.Tensor] = None):
+        """Local launch on a device-resident witness; returns the (not yet reduced) verdict tensors."""
+        none = 1 << 62
+        monotone = self.rows.shape[0] < 2 or bool(np.all(np.diff(self.rows) > 0))
+        res_vec = None
+        with torch.cuda.stream(self._stream):
+            self._res.copy_(torch.tensor([0, -1], dtype=torch.int64), non_blocking=False)
+            if want_first and not monotone:
+                res_vec = torch.empty((self.rows.shape[0], 4), dtype=torch.int64, device=self._res.device)
+            self.r1cs.verify_dev(w.data_ptr(), self._res.data_ptr(), d_dots=dots.data_ptr() if dots is not None else 0,
+                                 d_residuals=res_vec.data_ptr() if res_vec is not None else 0)
+            verdict = torch.stack([self._res[0], self._flag[0].to(torch.int64)])
+            first = torch.full((1,), none, dtype=torch.int64, device=self._res.device)
+            if want_first and monotone:
+                # the kernel's first_bad is the smallest LOCAL row (unsigned, UINT64_MAX = none); local order is
+                # increasing in the global row number here, so it maps straight to the global row
+                pos = self._res[1:2]
+                rows = torch.from_numpy(self.rows).to(pos.device)
+                first = torch.where(pos < 0, first, rows[pos.clamp(min=0, max=rows.shape[0] - 1)])
+            elif want_first:
+                # block-cyclic ownership: local order is not global order; take the residual vector (on request only)
+                self.ctx.dev_to_canonical(res_vec.shape[0], res_vec.data_ptr(), res_vec.data_ptr())
+                bad = (res_vec != 0).any(dim=1)
+                rows = torch.from_numpy(self.rows).to(bad.device)
+                first = torch.where(bad, rows, torch.full_like(rows, none)).min().reshape(1)
+        self._stream.synchronize()
+        return verdict, first
+
+    def dots(self, w, out: torch.Tensor):
+        """<A_i,w>, <B_i,w>, <C_i,w> of the local rows into out (3 * rows elements), plus the local verdict."""
+        if self._local_dots is not None:
+            out.copy_(self._local_dots(self.local_mats, self.m, w))
+            n_bad, _ = self._local_verify(self.local_mats, self.m, w, self.rows)
+            return torch.tensor([n_bad, 0], dtype=torch.int64), torch.tensor([1 << 62], dtype=torch.int64)
+        return self.verify_dev(w, dots=out)
+
+    def _reduce(self, verdict: torch.Tensor, first: torch.Tensor, want_first: bool) -> Tuple[bool, int, int]:
         if self.world > 1:
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)          # THE verdict collective
-            dist.all_reduce(first, op=dist.ReduceOp.MIN, group=self.group)
-        n_bad = int(cnt[0])
+            dist.all_reduce(verdict, op=dist.ReduceOp.SUM, group=self.group)          # THE verdict collective
+            if want_first:
+                dist.all_reduce(first, op=dist.ReduceOp.MIN, group=self.group)
+        n_bad, noncanon = int(verdict[0]), int(verdict[1])
+        if noncanon:
+            from ._lib import AcxError, STATUS
+            raise AcxError(STATUS["NONCANONICAL"], "element >= p")
         fb = int(first[0])
-        return n_bad == 0, n_bad, (fb if n_bad else U64_MAX)
+        return n_bad == 0, n_bad, (fb if (n_bad and want_first) else U64_MAX)
 
 
 # ------------------------------------------------------------------------------------ distributed NTT
 class LocalOps:
-    """Per-rank kernels the distributed NTT is built from.  Tensors are int64 views of field
-    elements, shape (..., 4), in whatever element format the implementation uses."""
+    """Per-rank kernels the distributed pipeline is built from.  Tensors are int64 views of field
+    elements, shape (count, 4), in whatever element format the implementation uses."""
 
-    def ntt(self, t: torch.Tensor, log_n: int, inverse: bool) -> None:
+    def dist_step(self, src: torch.Tensor, dst: torch.Tensor, log_n: int, log_r: int, world: int, rank: int,
+                  inverse: bool, step: int, shift: Optional[int]) -> None:
         raise NotImplementedError
 
-    def twiddle(self, t: torch.Tensor, log_n_total: int, row0: int, col0: int, inverse: bool) -> None:
+    def pointwise_h(self, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, out: torch.Tensor, log_n: int, shift: int) -> None:
+        """out = (a*b - c) / (shift^N - 1) elementwise (src/QAP.hs:325-327 on the coset)."""
         raise NotImplementedError
 
 
 class HipOps(LocalOps):
     """libacx kernels on dev-format CUDA tensors (the product path).  libacx launches on its
     context's own HIP stream; each call is fenced against torch's current stream in both
-    directions so that torch-side transposes and RCCL collectives order correctly around it."""
+    directions so that RCCL collectives (on torch's stream) order correctly around it."""
 
     def __init__(self, ctx: Context):
         self.ctx = ctx
@@ -135,13 +250,12 @@ class HipOps(LocalOps):
         if cur.cuda_stream != self._ext.cuda_stream:
             cur.wait_stream(self._ext)
 
-    def ntt(self, t, log_n, inverse):
-        assert t.is_cuda and t.is_contiguous()
-        self._fenced(lambda: self.ctx.ntt_dev(t.data_ptr(), log_n, t.numel() // 4 >> log_n, inverse=inverse))
+    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift):
+        assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()
+        self._fenced(lambda: self.ctx.ntt_dist_step_dev(src.data_ptr(), dst.data_ptr(), log_n, log_r, world, rank, inverse, step, shift))
 
-    def twiddle(self, t, log_n_total, row0, col0, inverse):
-        assert t.is_cuda and t.is_contiguous() and t.dim() == 3
-        self._fenced(lambda: self.ctx.ntt_twiddle_dev(t.data_ptr(), log_n_total, t.shape[0], t.shape[1], row0, col0, inverse))
+    def pointwise_h(self, a, b, c, out, log_n, shift):
+        self._fenced(lambda: self.ctx.qap_pointwise_dev(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), a.shape[0], log_n, shift))
 
 
 class DistributedNTT:
@@ -150,63 +264,94 @@ class DistributedNTT:
 
         X[k1 + k2 R] = sum_{i2} w_C^{i2 k2} * w_N^{i2 k1} * ( sum_{i1} w_R^{i1 k1} x[i1 C + i2] )
 
-    forward():  input  = this rank's COLUMN block  x[i1*C + i2], i2 in [g C/W, (g+1) C/W), as (R, C/W, 4)
-                output = this rank's k1 block      X[k1 + k2*R], k1 in [g R/W, (g+1) R/W), as (R/W, C, 4)
-    inverse() maps the output layout back to the input layout.  One all-to-all each way
-    (N*32*(W-1)/W bytes over xGMI, every link busy); no second exchange because a pipeline of
-    transforms (the 7 NTTs of h(x)) alternates the two layouts."""
+    Local layouts (include/acx.h, acx_ntt_dist_step_dev), N/W elements each:
+        COLS [i2l][i1]   x[i1*C + g*C/W + i2l]          ROWS [kl][k2]   X[(g*R/W + kl) + k2*R]
+    forward(): COLS -> ROWS, inverse(): ROWS -> COLS.  One all-to-all each way (N*32*(W-1)/W bytes over xGMI,
+    every link busy); a pipeline of transforms (the 7 NTTs of h(x)) alternates the two layouts, so nothing is
+    ever re-ordered in between."""
 
     def __init__(self, log_n: int, ops: LocalOps, group=None, log_r: Optional[int] = None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world, self.rank = _world(group)
         self.log_n = log_n
         self.log_r = log_r if log_r is not None else log_n // 2
         self.log_c = log_n - self.log_r
         self.R, self.C = 1 << self.log_r, 1 << self.log_c
         if self.R % self.world or self.C % self.world:
             raise ValueError("world size must divide both factors of N")
+        self.local = (1 << log_n) // self.world
         self.ops = ops
+        self._send = self._recv = None
 
     # -- layout helpers (tests / single-rank users) ---------------------------------------------
-    def scatter_input(self, x_full: torch.Tensor) -> torch.Tensor:
+    def cols_indices(self) -> np.ndarray:
+        """Natural index i of every element of this rank's COLS block, in local order."""
         cw = self.C // self.world
-        return x_full.reshape(self.R, self.C, 4)[:, self.rank * cw:(self.rank + 1) * cw].contiguous()
+        i2 = (self.rank * cw + np.arange(cw, dtype=np.int64)).reshape(-1, 1)
+        i1 = np.arange(self.R, dtype=np.int64).reshape(1, -1)
+        return (i1 * self.C + i2).reshape(-1)
 
-    def output_indices(self) -> torch.Tensor:
-        """Natural index k = k1 + k2*R of every element of this rank's output block (R/W, C)."""
-        rw = self.R // self.world
-        k1 = torch.arange(self.rank * rw, (self.rank + 1) * rw).reshape(-1, 1)
-        k2 = torch.arange(self.C).reshape(1, -1)
-        return k1 + k2 * self.R
+    def rows_indices(self) -> np.ndarray:
+        """Natural index k = k1 + k2*R of every element of this rank's ROWS block, in local order."""
+        return cyclic_rows(self.log_n, self.log_r, self.world, self.rank)
 
-    def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
+    def _buffers(self, like: torch.Tensor):
+        if self._send is None or self._send.device != like.device or self._send.dtype != like.dtype:
+            self._send = torch.empty((self.local, 4), dtype=like.dtype, device=like.device)
+            self._recv = torch.empty_like(self._send)
+        return self._send, self._recv
+
+    def _all_to_all(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return send
-        recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)
         return recv
 
-    def forward(self, x_cols: torch.Tensor) -> torch.Tensor:
-        W, R, C = self.world, self.R, self.C
-        cw, rw = C // W, R // W
-        y = x_cols.permute(1, 0, 2).contiguous()                       # (C/W, R): columns contiguous
-        self.ops.ntt(y, self.log_r, False)                             # pass 1: C/W transforms of length R
-        self.ops.twiddle(y, self.log_n, self.rank * cw, 0, False)      # * w_N^(i2 * k1)
-        send = y.reshape(cw, W, rw, 4).permute(1, 0, 2, 3).contiguous()  # (W, C/W, R/W): tile h -> rank h
-        recv = self._all_to_all(send)                                  # from rank g: its i2 block, my k1 block
-        z = recv.reshape(C, rw, 4).permute(1, 0, 2).contiguous()       # (R/W, C)
-        self.ops.ntt(z, self.log_c, False)                             # pass 2: R/W transforms of length C
-        return z
+    def _run(self, x: torch.Tensor, out: Optional[torch.Tensor], inverse: bool, shift: Optional[int]) -> torch.Tensor:
+        assert x.shape == (self.local, 4) and x.is_contiguous()
+        if out is None:
+            out = torch.empty_like(x)
+        send, recv = self._buffers(x)
+        a = (self.log_n, self.log_r, self.world, self.rank, inverse)
+        self.ops.dist_step(x, send, *a, 0, shift)
+        got = self._all_to_all(send, recv)
+        self.ops.dist_step(got, out, *a, 1, shift)
+        return out
 
-    def inverse(self, x_rows: torch.Tensor) -> torch.Tensor:
-        W, R, C = self.world, self.R, self.C
-        cw, rw = C // W, R // W
-        z = x_rows.contiguous().clone()
-        self.ops.ntt(z, self.log_c, True)                              # (R/W, C), scaled by 1/C
-        send = z.permute(1, 0, 2).reshape(W, cw, rw, 4).contiguous()   # (W, C/W, R/W): i2 block g -> rank g
-        recv = self._all_to_all(send)                                  # from rank h: its k1 block
-        y = recv.permute(1, 0, 2, 3).reshape(cw, R, 4).contiguous()    # (C/W, R)
-        self.ops.twiddle(y, self.log_n, self.rank * cw, 0, True)
-        self.ops.ntt(y, self.log_r, True)                              # scaled by 1/R
-        return y.permute(1, 0, 2).contiguous()                         # (R, C/W)
+    def forward(self, cols: torch.Tensor, out: Optional[torch.Tensor] = None, shift: Optional[int] = None) -> torch.Tensor:
+        return self._run(cols, out, False, shift)
+
+    def inverse(self, rows: torch.Tensor, out: Optional[torch.Tensor] = None, shift: Optional[int] = None) -> torch.Tensor:
+        return self._run(rows, out, True, shift)
+
+
+class DistributedQapH:
+    """`verificationWitness` (src/QAP.hs:292-327, delta = 0) over all GPUs: h = (L*R - O) / (x^N - 1).
+
+    Rows are owned block-cyclically (ShardedR1CS.from_cyclic), so the residual kernel's <A_i,w>, <B_i,w>, <C_i,w>
+    ARE the ROWS layout of three evaluation vectors.  Then 3 inverse transforms (-> coefficients, COLS), 3 forward
+    coset transforms (-> ROWS), the pointwise quotient, 1 inverse coset transform: h's coefficients in COLS layout
+    (rank g holds h[i1*C + g*C/W + i2l]).  Seven all-to-alls, one verdict all-reduce."""
+
+    def __init__(self, sharded: ShardedR1CS, ntt: DistributedNTT, generator: int):
+        assert sharded.rows.shape[0] == ntt.local
+        self.sharded, self.ntt, self.g = sharded, ntt, generator
+        self._bufs = None
+
+    def run(self, w) -> Tuple[torch.Tensor, bool]:
+        """w: the replicated witness (device tensor in dev format on the product path)."""
+        nt, L = self.ntt, self.ntt.local
+        if self._bufs is None:
+            dev = w.device if isinstance(w, torch.Tensor) else "cpu"
+            self._bufs = (torch.zeros((3 * L, 4), dtype=torch.int64, device=dev),
+                          torch.empty((3 * L, 4), dtype=torch.int64, device=dev))
+        dots, tmp = self._bufs
+        verdict, first = self.sharded.dots(w, dots)                       # rows of padding give 0
+        for k in range(3):
+            nt.inverse(dots[k * L:(k + 1) * L], out=tmp[k * L:(k + 1) * L])
+        for k in range(3):
+            nt.forward(tmp[k * L:(k + 1) * L], out=dots[k * L:(k + 1) * L], shift=self.g)
+        nt.ops.pointwise_h(dots[:L], dots[L:2 * L], dots[2 * L:], tmp[:L], nt.log_n, self.g)
+        h = nt.inverse(tmp[:L], out=tmp[L:2 * L], shift=self.g)
+        ok, _, _ = self.sharded._reduce(verdict, first, False)
+        return h, ok

@@ -138,3 +138,49 @@ def mulgraph(n: int, n_in: int = 1024, k: int = 2, window: int = 4096, seed: int
     circ = Circuit(field, gl, (kind, tok_ofs, tok_op, tok_arg, scalars, aff_wires, wire_ofs, wires))
     inputs = random_fr(n_in, seed, 12, field)
     return SynthCircuit(circ, inputs, n, n_in, k)
+
+
+class BlockSystem:
+    """`blocks` block-diagonal copies of one mulgraph system that share only the constant wire: the shape of
+    BASELINE.json configs[3] (2^24 constraints = 256 x 2^16) without ever materialising it on one host.  Any
+    subset of the global rows -- e.g. one rank's block-cyclic share -- is produced directly (`rows_of`), so every
+    process marshals only what it owns."""
+
+    def __init__(self, base: SynthCircuit, blocks: int):
+        self.base, self.blocks = base, blocks
+        self.mats = base.rows()
+        self.n0 = base.circuit.n_rows
+        self.m0 = base.circuit.m
+        self.n = self.n0 * blocks
+        self.m = 1 + blocks * (self.m0 - 1)
+        self._w0: Optional[np.ndarray] = None
+
+    def witness(self) -> np.ndarray:
+        if self._w0 is None:
+            self._w0 = self.base.witness()
+        return np.concatenate([self._w0[:1]] + [self._w0[1:]] * self.blocks)
+
+    def wire(self, block: int, k: int) -> int:
+        """global index of wire k (>= 1) of one block"""
+        return 1 + block * (self.m0 - 1) + (k - 1)
+
+    def rows_of(self, rows: np.ndarray) -> Tuple[Tuple[np.ndarray, np.ndarray, np.ndarray], ...]:
+        """CSR triples (A, B, C) of the given global rows, in the given order; indices >= n are empty rows
+        (the zero padding of the evaluation domain)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        live = rows < self.n
+        blk = np.where(live, rows // self.n0, 0)
+        loc = np.where(live, rows % self.n0, 0)
+        out = []
+        for rowptr, col, val in self.mats:
+            rp = np.asarray(rowptr, dtype=np.int64)
+            lens = np.where(live, rp[loc + 1] - rp[loc], 0)
+            new_rp = np.concatenate([[0], np.cumsum(lens)])
+            total = int(new_rp[-1])
+            # entry e of output row j comes from base entry rp[loc[j]] + (e - new_rp[j])
+            owner = np.repeat(np.arange(rows.shape[0], dtype=np.int64), lens)
+            src = rp[loc][owner] + (np.arange(total, dtype=np.int64) - new_rp[:-1][owner])
+            c = col[src].astype(np.int64)
+            c = np.where(c == 0, 0, c + blk[owner] * (self.m0 - 1))
+            out.append((new_rp.astype(np.uint32), c.astype(np.uint32), np.ascontiguousarray(val[src])))
+        return tuple(out)

@@ -242,12 +242,29 @@ int acx_ntt_dev(acx_ctx* ctx, uint32_t log_n, uint64_t batch, int inverse, const
  * d_result {n_bad, first_bad} accumulates like acx_r1cs_verify_dev (n_bad != 0 <=> `Nothing`).  delta may be NULL. */
 int acx_qap_h_dev(acx_r1cs* r, const void* d_witness, const acx_fr* delta, void* d_h, uint64_t* d_result);
 
-/* Twiddle step of a four-step / distributed NTT of length 2^log_n = R*C: the rows x cols tile at
- * (row0, col0) of the R x C matrix is multiplied elementwise by omega_N^((row0+r)*(col0+c))
- * (omega_N^-1 when inverse).  The RCCL all-to-all transpose between the two passes lives in the
- * host layer (one process per GPU). */
-int acx_ntt_twiddle_dev(acx_ctx* ctx, uint32_t log_n, int inverse, uint64_t rows, uint64_t cols,
-                        uint64_t row0, uint64_t col0, void* d_data);
+/* Local step of the DISTRIBUTED four-step NTT (replaces galois-fft at src/QAP.hs:521-524 when one
+ * transform spans several GPUs, BASELINE.json configs[3]).  N = 2^log_n = R*C with R = 2^log_r; index split
+ * i = i1*C + i2 (input side), k = k1 + k2*R (output side); `world` ranks (power of two dividing R and C), one
+ * process per GPU; rank g owns the i2 block g of the input side and the k1 block g of the output side.
+ * Local layouts, N/world dev elements each:
+ *     COLS  [i2l][i1]         x[i1*C + g*C/W + i2l]
+ *     ROWS  [kl][k2]          X[(g*R/W + kl) + k2*R]
+ *     XCHG  [peer][kl][i2l]   W contiguous chunks of (R/W)*(C/W) elements = the send / receive buffer of ONE
+ *                             all-to-all (RCCL ncclAllToAll / torch all_to_all_single), issued by the host
+ *   forward (inverse = 0):  step 0: COLS -> XCHG,  all-to-all,  step 1: XCHG -> ROWS
+ *   inverse (inverse = 1):  step 0: ROWS -> XCHG,  all-to-all,  step 1: XCHG -> COLS
+ * Each step is one kernel launch: the transposes are strides of the pass, the w_N^(i2*k1) twiddle (and the 1/N of
+ * an inverse transform) is the kernel's closing multiplication from tables.  shift != NULL: coset transform
+ * (forward evaluates on shift*<omega>, inverse undoes it).  5 <= log_r, log_n - log_r <= 12; d_in != d_out.
+ * world = 1 is the degenerate case (no exchange needed: XCHG of step 0 is the input of step 1). */
+int acx_ntt_dist_step_dev(acx_ctx* ctx, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse,
+                          int step, const acx_fr* shift, const void* d_in, void* d_out);
+
+/* The pointwise step of h(x) on a coset (src/QAP.hs:325-327 in evaluation form): out[i] = (a[i]*b[i] - c[i]) /
+ * (shift^N - 1), N = 2^log_n, on `count` dev elements (any slice of the evaluation vectors: the operation is
+ * layout agnostic, which is what lets the distributed pipeline keep its block layouts). */
+int acx_qap_pointwise_dev(acx_ctx* ctx, uint32_t log_n, uint64_t count, const acx_fr* shift, const void* d_a,
+                          const void* d_b, const void* d_c, void* d_out);
 
 /* Batched verification: `count` independent (constraint system, witness) pairs checked by ONE
  * kernel launch -- the shape of the reference's property tests, `all (verifyAssignment qap .

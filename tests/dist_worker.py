@@ -1,6 +1,7 @@
 """Worker for tests/test_distributed_cpu.py: world_size-2 (or more) gloo run of the multi-GPU host
-layer with oracle-backed local kernels (the distributed LOGIC is what is under test here; the HIP
-local kernels are covered by the -m gpu suite)."""
+layer with oracle-backed local kernels (the distributed LOGIC is what is under test here -- row
+ownership, layouts, the exchange, the verdict collective; the HIP local kernels are covered by the
+-m gpu suite against the same contract)."""
 import importlib
 import os
 import sys
@@ -12,72 +13,147 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from oracle import ref_qap as R                      # noqa: E402
-from oracle.c_oracle import COracle                  # noqa: E402
+from oracle.c_oracle import COracle, ints_to_limbs, limbs_to_ints      # noqa: E402
 
 par = importlib.import_module("arithmetic-circuits_amd.parallel")
 synth = importlib.import_module("arithmetic-circuits_amd.synth")
 
 
+def _ints(t):
+    return limbs_to_ints(t.numpy().view(np.uint64).reshape(-1, 4))
+
+
+def _tensor(vals):
+    return torch.from_numpy(ints_to_limbs(vals).view(np.int64)).reshape(-1, 4)
+
+
 class OracleOps(par.LocalOps):
-    """Local transforms done by the CPU oracle on canonical elements (test double)."""
+    """The layout contract of acx_ntt_dist_step_dev (include/acx.h) restated with the CPU oracle on canonical
+    elements (test double).  The 1/N of an inverse transform is split 1/C * 1/R over the two steps here, while
+    the product folds it into step 0's twiddles: only end-to-end results are comparable, which is what is tested."""
 
     def __init__(self, orc):
         self.orc = orc
 
-    def ntt(self, t, log_n, inverse):
-        a = t.numpy().view(np.uint64).reshape(-1, 4)
-        out = self.orc.ntt(a, log_n, inverse=inverse)
-        t.copy_(torch.from_numpy(out.view(np.int64)).reshape(t.shape))
+    def _ntt(self, vals, log_len, inverse):
+        return limbs_to_ints(self.orc.ntt(ints_to_limbs(vals), log_len, inverse=inverse))
 
-    def twiddle(self, t, log_n_total, row0, col0, inverse):
+    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift):
         p = self.orc.p
-        w = self.orc.root_of_unity(log_n_total)
+        N, R = 1 << log_n, 1 << log_r
+        C = N // R
+        rw, cw = R // world, C // world
+        w = self.orc.root_of_unity(log_n)
         if inverse:
             w = pow(w, -1, p)
-        from oracle.c_oracle import ints_to_limbs, limbs_to_ints
-        rows, cols = t.shape[0], t.shape[1]
-        vals = limbs_to_ints(t.numpy().view(np.uint64).reshape(-1, 4))
-        out = [v * pow(w, (row0 + i // cols) * (col0 + i % cols), p) % p for i, v in enumerate(vals)]
-        t.copy_(torch.from_numpy(ints_to_limbs(out).view(np.int64)).reshape(t.shape))
+        a = _ints(src)
+        out = [0] * (N // world)
+        if not inverse and step == 0:            # COLS -> XCHG
+            for i2l in range(cw):
+                i2 = rank * cw + i2l
+                col = a[i2l * R:(i2l + 1) * R]
+                if shift is not None:
+                    col = [x * pow(shift, i1 * C + i2, p) % p for i1, x in enumerate(col)]
+                y = self._ntt(col, log_r, False)
+                for k1 in range(R):
+                    out[k1 * cw + i2l] = y[k1] * pow(w, i2 * k1, p) % p
+        elif not inverse:                        # XCHG -> ROWS
+            for kl in range(rw):
+                vec = [a[s * rw * cw + kl * cw + i2l] for s in range(world) for i2l in range(cw)]
+                out[kl * C:(kl + 1) * C] = self._ntt(vec, log_n - log_r, False)
+        elif step == 0:                          # ROWS -> XCHG
+            for kl in range(rw):
+                k1 = rank * rw + kl
+                y = self._ntt(a[kl * C:(kl + 1) * C], log_n - log_r, True)
+                for i2 in range(C):
+                    out[(i2 // cw) * rw * cw + kl * cw + (i2 % cw)] = y[i2] * pow(w, i2 * k1, p) % p
+        else:                                    # XCHG -> COLS
+            for i2l in range(cw):
+                i2 = rank * cw + i2l
+                x = self._ntt([a[k1 * cw + i2l] for k1 in range(R)], log_r, True)
+                if shift is not None:
+                    si = pow(shift, -1, p)
+                    x = [v * pow(si, i1 * C + i2, p) % p for i1, v in enumerate(x)]
+                out[i2l * R:(i2l + 1) * R] = x
+        dst.copy_(_tensor(out))
+
+    def pointwise_h(self, a, b, c, out, log_n, shift):
+        p = self.orc.p
+        zinv = pow(pow(shift, 1 << log_n, p) - 1, -1, p)
+        out.copy_(_tensor([(x * y - z) * zinv % p for x, y, z in zip(_ints(a), _ints(b), _ints(c))]))
 
 
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     orc = COracle("bn254")
+    p = orc.p
 
     # ---- sharded R1CS check: verdict identical on all ranks and equal to the unsharded oracle
     s = synth.mulgraph(1 << 11, n_in=32, window=128, seed=99)
     mats, w = s.rows(), s.witness()
     n, m = s.circuit.n_rows, s.circuit.m
 
-    def local_verify(lm, m_, wit):
-        _, nbad, first = orc.r1cs_residuals(len(lm[0][0]) - 1, m_, *lm, wit, want_residuals=False)
-        return nbad, (first if nbad else 0)
+    def local_verify(lm, m_, wit, rows):
+        res, nbad, _ = orc.r1cs_residuals(len(lm[0][0]) - 1, m_, *lm, wit)
+        badrows = rows[res.any(axis=1)]
+        return nbad, (int(badrows.min()) if nbad else 0)
 
-    sh = par.ShardedR1CS(mats, m, local_verify=local_verify)
-    assert sh.bounds[0] == 0 and sh.bounds[-1] == n and all(a <= b for a, b in zip(sh.bounds, sh.bounds[1:]))
-    assert sh.verify(w) == (True, 0, par.U64_MAX)
+    def local_dots(lm, m_, wit):
+        wi = limbs_to_ints(wit)
+        vals = []
+        for rowptr, col, val in lm:
+            v = limbs_to_ints(val)
+            vals += [sum(v[e] * wi[int(col[e])] for e in range(int(rowptr[i]), int(rowptr[i + 1]))) % p
+                     for i in range(len(rowptr) - 1)]
+        return _tensor(vals)
+
     bad = w.copy()
     for k in (40, 900, 2000):
         bad[k, 0] ^= np.uint64(1)
     _, want_bad, want_first = orc.r1cs_residuals(n, m, *mats, bad, want_residuals=False)
-    assert sh.verify(bad) == (False, want_bad, want_first), (sh.verify(bad), want_bad, want_first)
+    sh = par.ShardedR1CS.from_slabs(mats, m, local_verify=local_verify)
+    assert sh.bounds[0] == 0 and sh.bounds[-1] == n and all(a <= b for a, b in zip(sh.bounds, sh.bounds[1:]))
+    assert sh.verify(w) == (True, 0, par.U64_MAX)
+    assert sh.verify(bad) == (False, want_bad, par.U64_MAX)                  # one collective: no first_bad
+    assert sh.verify(bad, want_first=True) == (False, want_bad, want_first)
+    # block-cyclic ownership, rows marshalled per rank from a row source (here: gathered from the host CSR)
+    log_n, log_r = 11, 5
+    source = lambda rows: tuple(par.gather_rows(mt, rows) for mt in mats)
+    shc = par.ShardedR1CS.from_cyclic(source, n, m, log_n, log_r, local_verify=local_verify, local_dots=local_dots)
+    own = par.cyclic_rows(log_n, log_r, world, rank)
+    assert np.array_equal(shc.rows, own) and len(own) == (1 << log_n) // world
+    allrows = [torch.zeros(len(own), dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allrows, torch.from_numpy(own))
+    assert sorted(torch.cat(allrows).tolist()) == list(range(1 << log_n))      # a partition of the padded domain
+    assert shc.verify(w) == (True, 0, par.U64_MAX)
+    assert shc.verify(bad, want_first=True) == (False, want_bad, want_first)
 
-    # ---- distributed four-step NTT == single transform, forward and inverse
+    # ---- distributed four-step NTT == single transform: forward, inverse, coset, odd digits
     for log_n, log_r in ((8, 4), (9, 4), (10, 6)):
         N = 1 << log_n
         x = synth.random_fr(N, 7, log_n)
-        want = orc.ntt(x, log_n)
         d = par.DistributedNTT(log_n, OracleOps(orc), log_r=log_r)
         xt = torch.from_numpy(x.view(np.int64))
-        out = d.forward(d.scatter_input(xt))
-        idx = d.output_indices().reshape(-1).numpy()
-        got = out.reshape(-1, 4).numpy().view(np.uint64)
-        assert np.array_equal(got, want[idx]), f"forward mismatch log_n={log_n} rank={rank}"
-        back = d.inverse(out)
-        assert torch.equal(back, d.scatter_input(xt)), f"inverse mismatch log_n={log_n}"
+        mine = xt[d.cols_indices()].contiguous()
+        for shift in (None, 5):
+            want = orc.ntt(x, log_n, shift=shift)
+            out = d.forward(mine, shift=shift)
+            got = out.numpy().view(np.uint64)
+            assert np.array_equal(got, want[d.rows_indices()]), f"forward mismatch log_n={log_n} rank={rank} shift={shift}"
+            back = d.inverse(out, shift=shift)
+            assert torch.equal(back, mine), f"inverse mismatch log_n={log_n} shift={shift}"
+
+    # ---- distributed h(x): residual dots in ROWS ownership -> 7 transforms -> h in COLS ownership
+    log_n, log_r = 11, 5
+    dn = par.DistributedNTT(log_n, OracleOps(orc), log_r=log_r)
+    qh = par.DistributedQapH(shc, dn, orc.generator)
+    h, ok = qh.run(w)
+    want_h, want_ok = orc.qap_h(n, m, log_n, *mats, w)
+    assert ok and want_ok
+    assert np.array_equal(h.numpy().view(np.uint64), want_h[:1 << log_n][dn.cols_indices()]), "distributed h(x) mismatch"
+    _, ok_bad = qh.run(bad)
+    assert not ok_bad
     dist.barrier()
     if rank == 0:
         print("DIST_OK world", world)

@@ -22,14 +22,31 @@ synth = importlib.import_module("arithmetic-circuits_amd.synth")
 
 
 class StagedNTT(par.DistributedNTT):
-    def _all_to_all(self, send):
+    def _all_to_all(self, send, recv):
         if self.world == 1:
             return send
         torch.cuda.synchronize()
         s = send.cpu()
         r = torch.empty_like(s)
         dist.all_to_all_single(r, s, group=self.group)
-        return r.to(send.device)
+        recv.copy_(r)
+        return recv
+
+
+def dev(ctx, arr):
+    t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy()).cuda()
+    torch.cuda.synchronize()
+    ctx.dev_from_canonical(t.shape[0], t.data_ptr(), t.data_ptr())
+    ctx.sync()
+    return t
+
+
+def canon(ctx, t):
+    c = torch.empty_like(t)
+    torch.cuda.synchronize()
+    ctx.dev_to_canonical(t.shape[0], t.data_ptr(), c.data_ptr())
+    ctx.sync()
+    return c.cpu().numpy().view(np.uint64).reshape(-1, 4)
 
 
 def main():
@@ -43,50 +60,42 @@ def main():
     s = synth.mulgraph(1 << 14, n_in=64, window=512, seed=7)
     mats, w = s.rows(), s.witness()
     n, m = s.circuit.n_rows, s.circuit.m
-    sh = par.ShardedR1CS(mats, m, ctx=ctx)
-    assert sh.r1cs is not None and sh.hi - sh.lo < n
+    sh = par.ShardedR1CS.from_slabs(mats, m, ctx=ctx)
+    assert sh.r1cs is not None and sh.rows.shape[0] < n
     assert sh.verify(w) == (True, 0, par.U64_MAX)
     bad = w.copy()
     for k in (77, 5000, 16000):
         bad[k, 0] ^= np.uint64(1)
     _, want_bad, want_first = orc.r1cs_residuals(n, m, *mats, bad, want_residuals=False, nthreads=4)
-    assert sh.verify(bad) == (False, want_bad, want_first), (sh.verify(bad), want_bad, want_first)
+    assert sh.verify(bad) == (False, want_bad, par.U64_MAX)
+    assert sh.verify(bad, want_first=True) == (False, want_bad, want_first), (sh.verify(bad, want_first=True), want_bad, want_first)
 
-    # ---- four-step NTT with the HIP local transforms
+    # ---- four-step NTT with the HIP local steps: forward / inverse / coset, even and odd digits
     ops = par.HipOps(ctx)
-    for log_n in (12, 16):
+    for log_n, log_r in ((12, 6), (15, 7), (16, 8)):
         N = 1 << log_n
         x = synth.random_fr(N, 11, log_n)
-        want = orc.ntt(x, log_n, nthreads=4)
-        xd = torch.from_numpy(x.view(np.int64).copy()).cuda()
-        torch.cuda.synchronize()
-        ctx.dev_from_canonical(N, xd.data_ptr(), xd.data_ptr())
-        ctx.sync()
-        d = StagedNTT(log_n, ops)
-        mine = d.scatter_input(xd)
-        out = d.forward(mine)
-        torch.cuda.synchronize(); ctx.sync()
-        flat = out.reshape(-1, 4).clone()             # the conversion below is in place: keep `out` in dev format
-        torch.cuda.synchronize()                      # the clone ran on torch's stream, libacx launches on its own
-        ctx.dev_to_canonical(flat.shape[0], flat.data_ptr(), flat.data_ptr())
-        ctx.sync()
-        got = flat.cpu().numpy().view(np.uint64)
-        idx = d.output_indices().reshape(-1).numpy()
-        assert np.array_equal(got, want[idx]), f"forward mismatch log_n={log_n} rank={rank}"
-        back = d.inverse(out)
-        torch.cuda.synchronize(); ctx.sync()
+        d = StagedNTT(log_n, ops, log_r=log_r)
+        mine = dev(ctx, x[d.cols_indices()])
+        for shift in (None, orc.generator):
+            want = orc.ntt(x, log_n, shift=shift, nthreads=4)
+            out = d.forward(mine, shift=shift)
+            assert np.array_equal(canon(ctx, out), want[d.rows_indices()]), f"forward mismatch log_n={log_n} rank={rank}"
+            back = d.inverse(out, shift=shift)
+            assert np.array_equal(canon(ctx, back), x[d.cols_indices()]), f"inverse mismatch log_n={log_n} rank={rank}"
 
-        def canonical(t):           # dev format is lazy (a value and value + p are the same element): compare canonically
-            c = t.reshape(-1, 4).clone()
-            torch.cuda.synchronize()
-            ctx.dev_to_canonical(c.shape[0], c.data_ptr(), c.data_ptr())
-            ctx.sync()
-            return c
-        cb, cm = canonical(back), canonical(mine)
-        if not torch.equal(cb, cm):
-            bad = (cb != cm).any(dim=1).reshape(back.shape[0], back.shape[1])
-            raise AssertionError(f"inverse mismatch log_n={log_n} rank={rank}: {int(bad.sum())} of {bad.numel()} elements, "
-                                 f"rows {bad.any(dim=1).nonzero().flatten()[:8].tolist()} cols {bad.any(dim=0).nonzero().flatten()[:8].tolist()}")
+    # ---- the whole C4 pipeline: block-cyclic rows marshalled per rank, distributed h(x) == oracle
+    log_n, log_r = 14, 7
+    source = lambda rows: tuple(par.gather_rows(mt, rows) for mt in mats)
+    shc = par.ShardedR1CS.from_cyclic(source, n, m, log_n, log_r, ctx=ctx)
+    assert shc.rows.shape[0] == n // world
+    assert shc.verify(bad, want_first=True) == (False, want_bad, want_first)
+    dn = StagedNTT(log_n, ops, log_r=log_r)
+    qh = par.DistributedQapH(shc, dn, orc.generator)
+    h, ok = qh.run(dev(ctx, w))
+    want_h, want_ok = orc.qap_h(n, m, log_n, *mats, w, nthreads=4)
+    assert ok and want_ok and np.array_equal(canon(ctx, h), want_h[:1 << log_n][dn.cols_indices()]), "distributed h(x) mismatch"
+    assert not qh.run(dev(ctx, bad))[1]
     dist.barrier()
     if rank == 0:
         print("dist gpu worker ok", world)
