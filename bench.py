@@ -165,6 +165,87 @@ def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
             "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6, "roofline": _hbm(alg, us)}
 
 
+def bench_distributed(ctx, a, world, rank, dist):
+    """configs[3] beside the headline (N > 1, or --force-dist on one GPU): the distributed four-step NTT at
+    N = 2^24 (one all-to-all per transform) and the distributed h(x) pipeline on a 2^24-constraint block system
+    (256 x 2^16 mulgraph blocks, rows marshalled per rank in block-cyclic ownership; 7 all-to-alls + 1 all-reduce).
+    Times are max over ranks.  Parity gates: transform round trip at 2^24 plus a full oracle comparison of the same
+    code path at 2^16; the pipeline must accept the satisfying witness and reject a corrupted one."""
+    par = importlib.import_module("arithmetic-circuits_amd.parallel")
+    from oracle.c_oracle import COracle
+    orc = COracle(a.field)
+    ops = par.HipOps(ctx)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def tmax(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def wall(fn, reps):
+        fn()
+        torch.cuda.synchronize(); ctx.sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(); ctx.sync()
+        return tmax((time.perf_counter() - t0) / reps)
+
+    out = {}
+    # --- parity of the distributed transform against the oracle at 2^16 (same kernels, same exchange)
+    ln = 16
+    d16 = par.DistributedNTT(ln, ops, log_r=8)
+    x16 = synth.random_fr(1 << ln, 31, 1, a.field)
+    got = _from_dev(ctx, d16.forward(to_dev(ctx, x16[d16.cols_indices()])), d16.local)
+    parity = bool(np.array_equal(got, orc.ntt(x16, ln, nthreads=os.cpu_count() or 1)[d16.rows_indices()]))
+    # --- 2^24 transform
+    ln, lr = a.dist_logn, a.dist_logn // 2
+    d = par.DistributedNTT(ln, ops, log_r=lr)
+    x = to_dev(ctx, synth.random_fr(d.local, 32 + rank, 1, a.field))
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    d.forward(x, out=y)
+    d.inverse(y, out=z)
+    torch.cuda.synchronize(); ctx.sync()
+    parity = parity and bool(np.array_equal(_from_dev(ctx, z, d.local), _from_dev(ctx, x, d.local)))
+    flip = [False]
+
+    def one():
+        flip[0] = not flip[0]
+        if flip[0]:
+            d.forward(x, out=y)
+        else:
+            d.inverse(y, out=z)
+
+    sec = wall(one, 10)
+    n = 1 << ln
+    out["dist_ntt"] = {"workload": f"distributed four-step NTT N=2^{ln} = 2^{lr} x 2^{ln - lr} over {world} rank(s), alternating forward/inverse",
+                       "parity_vs_oracle": parity, "us": sec * 1e6, "field_ops_per_s": 1.5 * n * ln / sec,
+                       "all_to_all_bytes_per_rank": (n // world) * 32 * (world - 1) // world,
+                       "roofline": _hbm(128 * n // world, sec * 1e6, note="per rank: 128*N/W algorithmic bytes")}
+    del x, y, z
+    # --- h(x) on the 2^24-constraint block system
+    blocks = n >> 16
+    bs = synth.BlockSystem(synth.mulgraph(1 << 16, seed=0xAC4, field=a.field), blocks)
+    sh = par.ShardedR1CS.from_cyclic(bs.rows_of, bs.n, bs.m, ln, lr, ctx=ctx)
+    qh = par.DistributedQapH(sh, d, orc.generator)
+    w = bs.witness()
+    dw = to_dev(ctx, w)
+    _, ok = qh.run(dw)
+    wb = w.copy()
+    wb[bs.wire(blocks - 1, 99), 0] ^= np.uint64(1)
+    _, ok_bad = qh.run(to_dev(ctx, wb))
+    sec = wall(lambda: qh.run(dw), 3)
+    out["dist_qap_h"] = {"workload": f"distributed verificationWitness h(x): {blocks} x 2^16-constraint mulgraph blocks = 2^{ln} constraints over "
+                                     f"{world} rank(s), block-cyclic rows, 7 all-to-alls + 1 all-reduce",
+                         "accepts_valid_rejects_corrupt": bool(ok and not ok_bad), "us": sec * 1e6,
+                         "constraints_per_s": bs.n / sec}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +261,8 @@ def main():
                          "multi-rank control flow be tested on a 1-GPU box")
     ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed launches before the warmup steps (clock ramp)")
     ap.add_argument("--sustain", type=float, default=0.5, help="seconds of extra K-step blocks for the median/min per-step figures")
+    ap.add_argument("--dist-logn", type=int, default=24, help="size of the distributed NTT / h(x) job timed when N > 1 or --force-dist")
+    ap.add_argument("--no-dist-pipeline", action="store_true", help="skip the distributed NTT / h(x) measurements of a multi-rank run")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     a = ap.parse_args()
@@ -339,6 +422,11 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
+    dist_extra = {}
+    if use_dist and not a.no_dist_pipeline and a.backend == "nccl":
+        del batches, neg_batch
+        systems.clear(); witnesses.clear()
+        dist_extra = bench_distributed(ctx, a, world, rank, dist)
     if rank == 0:
         total = world * a.copies * n * a.steps
         value = total / dt
@@ -352,12 +440,13 @@ def main():
                                    f"step, one batched launch (k=2, n_in=1024, window=4096, seeds 0xAC355+1000*rank+c)",
                        "constraints_per_step_per_gpu": a.copies * n, "nnz_per_step_per_gpu": nnz_total,
                        "single_system_launch_us": single_us,
-                       "field": a.field + "_fr", "parallelism": f"rows sharded x{world}, 1 verdict all-reduce per {ring} steps" if use_dist else "single GPU"},
+                       "field": a.field + "_fr", "parallelism": f"{world} rank(s) x {a.copies} independent systems (weak scaling), 1 verdict all-reduce per {ring} steps" if use_dist else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "acx::k_r1cs_sell", "kernel_us": kernel_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        out.update(dist_extra)
         if block_us:
             bs = sorted(block_us)
             out["sustained"] = {"blocks": len(bs), "steps_per_block": a.steps, "seconds": sum(bs) * a.steps * 1e-6,
