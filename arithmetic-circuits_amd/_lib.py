@@ -62,6 +62,7 @@ SYMBOLS = {
     "acx_circuit_valid": (_I, [_P, C.POINTER(_I)]),
     "acx_circuit_eval": (_I, [_P, _P, _P, _U64, _P, _P]),
     "acx_circuit_to_r1cs": (_I, [_P, _P, _P, _U64, C.POINTER(_P)]),
+    "acx_circuit_check_root_counts": (_I, [_P, _P, _U64]),
     "acx_circuit_nnz": (_I, [_P, C.POINTER(_U64 * 3)]),
     "acx_circuit_rows": (_I, [_P, _P, _U64, _I, _P, _P, _P]),
     "acx_r1cs_load": (_I, [_P, _U64, _U64, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), C.POINTER(_P)]),

@@ -78,11 +78,16 @@ public:
         if (!gl) { msg = "null gate list"; return ACX_ERR_INVALID_ARG; }
         n_gates = gl->n_gates;
         if (n_gates && (!gl->kind || !gl->tok_ofs || !gl->wire_ofs)) { msg = "null gate arrays"; return ACX_ERR_INVALID_ARG; }
-        kind.assign(gl->kind, gl->kind + n_gates);
-        tok_ofs.assign(gl->tok_ofs, gl->tok_ofs + 2 * n_gates + 1);
-        wire_ofs.assign(gl->wire_ofs, gl->wire_ofs + n_gates + 1);
-        if (n_gates == 0) { tok_ofs = {0}; wire_ofs = {0}; }
+        if (n_gates == 0) {                       // the empty circuit: the caller may pass NULL arrays
+            kind.clear(); tok_ofs = {0}; wire_ofs = {0};
+        } else {
+            kind.assign(gl->kind, gl->kind + n_gates);
+            tok_ofs.assign(gl->tok_ofs, gl->tok_ofs + 2 * n_gates + 1);
+            wire_ofs.assign(gl->wire_ofs, gl->wire_ofs + n_gates + 1);
+        }
         const uint64_t n_tok = tok_ofs.back(), n_w = wire_ofs.back();
+        if ((n_tok && (!gl->tok_op || !gl->tok_arg)) || (n_w && !gl->wires) || (gl->n_aff_wires && !gl->aff_wires) ||
+            (gl->n_scalars && !gl->scalars)) { msg = "null array with a nonzero count"; return ACX_ERR_INVALID_ARG; }
         for (size_t i = 0; i + 1 < tok_ofs.size(); ++i)
             if (tok_ofs[i] > tok_ofs[i + 1]) { msg = "tok_ofs not monotone"; return ACX_ERR_BAD_CIRCUIT; }
         for (size_t i = 0; i + 1 < wire_ofs.size(); ++i)
@@ -126,60 +131,64 @@ public:
         return ACX_OK;
     }
 
-    // affineCircuitToAffineMap on the token range starting at pos (advanced past the sub-tree).
-    void affine_map(uint64_t& pos, H256& cst, std::map<uint64_t, H256>& vec) const {
-        const uint8_t op = tok_op[pos];
-        const uint32_t arg = tok_arg[pos];
-        ++pos;
-        switch (op) {
-            case ACX_AFF_VAR:
-                cst = hf.zero();
-                vec.clear();
-                vec[flat(aff_wires[arg])] = hf.one();
-                break;
-            case ACX_AFF_CONST:
-                cst = scalars[arg];
-                vec.clear();
-                break;
-            case ACX_AFF_SCALARMUL: {
-                affine_map(pos, cst, vec);
-                cst = hf.mul(scalars[arg], cst);
-                for (auto& kv : vec) kv.second = hf.mul(scalars[arg], kv.second);
-                break;
-            }
-            default: {  // ADD: Map.unionWith (+)
-                H256 cr;
-                std::map<uint64_t, H256> vr;
-                affine_map(pos, cst, vec);
-                affine_map(pos, cr, vr);
-                cst = hf.add(cst, cr);
-                for (const auto& kv : vr) {
-                    auto it = vec.find(kv.first);
-                    if (it == vec.end()) vec.emplace(kv.first, kv.second);
+    // affineCircuitToAffineMap of the sub-tree whose pre-order tokens are [begin, end).  Iterative: the tokens
+    // are consumed right to left with an explicit value stack (a prefix expression read backwards is a postfix
+    // one), so a 10^5-term left-nested Add chain -- the natural foldl shape -- costs heap, not call stack.
+    // Add = Map.unionWith (+) (smaller map merged into the larger), ScalarMul scales constant and entries.
+    void affine_map(uint64_t begin, uint64_t end, H256& cst, std::map<uint64_t, H256>& vec) const {
+        struct Val { H256 cst; std::map<uint64_t, H256> vec; };
+        std::vector<Val> st;
+        for (uint64_t pos = end; pos-- > begin;) {
+            const uint8_t op = tok_op[pos];
+            const uint32_t arg = tok_arg[pos];
+            if (op == ACX_AFF_VAR) {
+                st.emplace_back();
+                st.back().cst = hf.zero();
+                st.back().vec[flat(aff_wires[arg])] = hf.one();
+            } else if (op == ACX_AFF_CONST) {
+                st.emplace_back();
+                st.back().cst = scalars[arg];
+            } else if (op == ACX_AFF_SCALARMUL) {
+                Val& v = st.back();
+                v.cst = hf.mul(scalars[arg], v.cst);
+                for (auto& kv : v.vec) kv.second = hf.mul(scalars[arg], kv.second);
+            } else {  // ADD: left operand is on top (it was read last)
+                Val l = std::move(st.back());
+                st.pop_back();
+                Val& r = st.back();
+                r.cst = hf.add(l.cst, r.cst);
+                if (l.vec.size() > r.vec.size()) std::swap(l.vec, r.vec);
+                for (const auto& kv : l.vec) {
+                    auto it = r.vec.find(kv.first);
+                    if (it == r.vec.end()) r.vec.emplace(kv.first, kv.second);
                     else it->second = hf.add(it->second, kv.second);
                 }
             }
         }
+        cst = st.back().cst;
+        vec = std::move(st.back().vec);
     }
 
-    // evalAffineCircuit: failed lookups are 0.
-    H256 affine_eval(uint64_t& pos, const std::vector<H256>& w, const std::vector<uint8_t>& assigned) const {
-        const uint8_t op = tok_op[pos];
-        const uint32_t arg = tok_arg[pos];
-        ++pos;
-        switch (op) {
-            case ACX_AFF_VAR: {
+    // evalAffineCircuit of the tokens [begin, end): failed lookups are 0.  Same right-to-left evaluation.
+    H256 affine_eval(uint64_t begin, uint64_t end, const std::vector<H256>& w, const std::vector<uint8_t>& assigned) const {
+        std::vector<H256> st;
+        for (uint64_t pos = end; pos-- > begin;) {
+            const uint8_t op = tok_op[pos];
+            const uint32_t arg = tok_arg[pos];
+            if (op == ACX_AFF_VAR) {
                 const uint64_t k = flat(aff_wires[arg]);
-                return assigned[k] ? w[k] : hf.zero();
-            }
-            case ACX_AFF_CONST: return scalars[arg];
-            case ACX_AFF_SCALARMUL: return hf.mul(affine_eval(pos, w, assigned), scalars[arg]);
-            default: {
-                const H256 l = affine_eval(pos, w, assigned);
-                const H256 r = affine_eval(pos, w, assigned);
-                return hf.add(l, r);
+                st.push_back(assigned[k] ? w[k] : hf.zero());
+            } else if (op == ACX_AFF_CONST) {
+                st.push_back(scalars[arg]);
+            } else if (op == ACX_AFF_SCALARMUL) {
+                st.back() = hf.mul(st.back(), scalars[arg]);
+            } else {
+                const H256 l = st.back();
+                st.pop_back();
+                st.back() = hf.add(l, st.back());
             }
         }
+        return st.back();
     }
 
     // gateToGenQAP over every gate, rows in gate order.
@@ -190,10 +199,8 @@ public:
             if (kind[g] == ACX_GATE_MUL) {
                 std::map<uint64_t, H256> l, r, o;
                 H256 lc, rc;
-                uint64_t pos = tok_ofs[2 * g];
-                affine_map(pos, lc, l);
-                pos = tok_ofs[2 * g + 1];
-                affine_map(pos, rc, r);
+                affine_map(tok_ofs[2 * g], tok_ofs[2 * g + 1], lc, l);
+                affine_map(tok_ofs[2 * g + 1], tok_ofs[2 * g + 2], rc, r);
                 l[0] = lc;  // constantQapSet (root, leftInputConst): a Var can never name column 0
                 r[0] = rc;
                 o[flat(gw[0])] = one;
@@ -254,10 +261,8 @@ public:
         for (uint64_t g = 0; g < n_gates; ++g) {
             const acx_wire* gw = &wires[wire_ofs[g]];
             if (kind[g] == ACX_GATE_MUL) {
-                uint64_t pos = tok_ofs[2 * g];
-                const H256 l = affine_eval(pos, w, assigned);
-                pos = tok_ofs[2 * g + 1];
-                const H256 r = affine_eval(pos, w, assigned);
+                const H256 l = affine_eval(tok_ofs[2 * g], tok_ofs[2 * g + 1], w, assigned);
+                const H256 r = affine_eval(tok_ofs[2 * g + 1], tok_ofs[2 * g + 2], w, assigned);
                 const uint64_t o = flat(gw[0]);
                 w[o] = hf.mul(l, r);
                 assigned[o] = 1;
@@ -375,18 +380,25 @@ public:
     }
 
 private:
+    // One well-formed pre-order tree starting at pos (advanced past it): every token opens as many
+    // sub-trees as its arity; the tree is complete when none is left open.  No recursion.
     bool check_tree(uint64_t& pos, uint64_t end, const acx_gate_list* gl) const {
-        if (pos >= end) return false;
-        const uint8_t op = tok_op[pos];
-        const uint32_t arg = tok_arg[pos];
-        ++pos;
-        switch (op) {
-            case ACX_AFF_VAR: return arg < gl->n_aff_wires;
-            case ACX_AFF_CONST: return arg < gl->n_scalars;
-            case ACX_AFF_SCALARMUL: return arg < gl->n_scalars && check_tree(pos, end, gl);
-            case ACX_AFF_ADD: return check_tree(pos, end, gl) && check_tree(pos, end, gl);
-            default: return false;
+        uint64_t open = 1;
+        while (open) {
+            if (pos >= end) return false;
+            const uint8_t op = tok_op[pos];
+            const uint32_t arg = tok_arg[pos];
+            ++pos;
+            --open;
+            switch (op) {
+                case ACX_AFF_VAR: if (arg >= gl->n_aff_wires) return false; break;
+                case ACX_AFF_CONST: if (arg >= gl->n_scalars) return false; break;
+                case ACX_AFF_SCALARMUL: if (arg >= gl->n_scalars) return false; open += 1; break;
+                case ACX_AFF_ADD: open += 2; break;
+                default: return false;
+            }
         }
+        return true;
     }
 };
 

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -26,6 +27,18 @@ static thread_local std::string g_last_error;
 static int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
+}
+
+// Nothing may propagate through the C ABI: host allocations sized by caller data can throw.
+template <class Fn>
+static int guarded(Fn&& fn) {
+    try {
+        return fn();
+    } catch (const std::bad_alloc&) {
+        return fail(ACX_ERR_OOM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(ACX_ERR_INVALID_ARG, std::string("unexpected exception: ") + e.what());
+    }
 }
 
 #define HIP_TRY(expr)                                                                         \
@@ -133,6 +146,7 @@ struct acx_naive {          // createPolynomials state for arbitrary distinct ro
 };
 
 struct acx_circuit {
+    int field = 0;
     HostCircuit hc;
     HostCsr rows[3];     // gateToGenQAP rows in gate order, built once
 };
@@ -868,24 +882,28 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
     if (!r) return fail(ACX_ERR_OOM, "host allocation failed");
     r->ctx = ctx; r->n = n; r->m = m; r->log_n = log_n;
     int rc = ACX_OK;
-    std::vector<uint32_t> rowptrs[3];
-    for (int k = 0; k < 3 && rc == ACX_OK; ++k) {
-        std::vector<uint32_t>& rowptr = rowptrs[k];
-        std::vector<uint32_t> col;
-        std::vector<acx_fr> val;
-        rc = normalise_csr(ctx->hf, n, m, mats[k], rowptr, col, val);
-        if (rc == ACX_OK && k == 2) {
-            static const uint8_t one32[32] = {1};
-            bool unit = true;
-            for (size_t e = 0; e < val.size() && unit; ++e) unit = std::memcmp(val[e].b, one32, 32) == 0;
-            r->unit_c = unit;
+    try {                                              // host vectors are sized by caller data
+        std::vector<uint32_t> rowptrs[3];
+        for (int k = 0; k < 3 && rc == ACX_OK; ++k) {
+            std::vector<uint32_t>& rowptr = rowptrs[k];
+            std::vector<uint32_t> col;
+            std::vector<acx_fr> val;
+            rc = normalise_csr(ctx->hf, n, m, mats[k], rowptr, col, val);
+            if (rc == ACX_OK && k == 2) {
+                static const uint8_t one32[32] = {1};
+                bool unit = true;
+                for (size_t e = 0; e < val.size() && unit; ++e) unit = std::memcmp(val[e].b, one32, 32) == 0;
+                r->unit_c = unit;
+            }
+            if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, col, val.data(), true, r->M[k]);
         }
-        if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, col, val.data(), true, r->M[k]);
-    }
-    if (rc == ACX_OK) rc = build_sell(r, rowptrs);
-    if (rc == ACX_OK) {
-        hipError_t e = hipMalloc((void**)&r->d_w, m * 32);
-        if (e != hipSuccess) rc = fail(ACX_ERR_OOM, "witness buffer allocation failed");
+        if (rc == ACX_OK) rc = build_sell(r, rowptrs);
+        if (rc == ACX_OK) {
+            hipError_t e = hipMalloc((void**)&r->d_w, m * 32);
+            if (e != hipSuccess) rc = fail(ACX_ERR_OOM, "witness buffer allocation failed");
+        }
+    } catch (const std::bad_alloc&) {
+        rc = fail(ACX_ERR_OOM, "host allocation failed");
     }
     if (rc != ACX_OK) {
         free_r1cs_device(r);
@@ -1038,14 +1056,26 @@ void* acx_ctx_stream(acx_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int acx_circuit_create(int field, const acx_gate_list* gates, acx_circuit** out) {
     if (!gates || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (field != ACX_FIELD_BN254_FR && field != ACX_FIELD_BLS12_381_FR) return fail(ACX_ERR_INVALID_ARG, "unknown field");
-    acx_circuit* c = new (std::nothrow) acx_circuit();
-    if (!c) return fail(ACX_ERR_OOM, "host allocation failed");
-    c->hc.hf = field == ACX_FIELD_BN254_FR ? HostField::make<Bn254Fr>() : HostField::make<Bls12381Fr>();
-    std::string msg;
-    const int rc = c->hc.init(gates, msg);
-    if (rc != ACX_OK) { delete c; return fail(rc, msg); }
-    c->hc.build_rows(c->rows[0], c->rows[1], c->rows[2]);
-    *out = c;
+    return guarded([&]() -> int {
+        std::unique_ptr<acx_circuit> c(new acx_circuit());
+        c->field = field;
+        c->hc.hf = field == ACX_FIELD_BN254_FR ? HostField::make<Bn254Fr>() : HostField::make<Bls12381Fr>();
+        std::string msg;
+        const int rc = c->hc.init(gates, msg);
+        if (rc != ACX_OK) return fail(rc, msg);
+        c->hc.build_rows(c->rows[0], c->rows[1], c->rows[2]);
+        *out = c.release();
+        return ACX_OK;
+    });
+}
+
+int acx_circuit_check_root_counts(const acx_circuit* c, const uint32_t* counts, uint64_t n_lists) {
+    if (!c || (n_lists && !counts)) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    // `zipWith gateToGenQAP rootsPerGate gates` (src/QAP.hs:539): list g must hold exactly the gate's row count
+    // (src/QAP.hs:444-445,474 panic otherwise); lists beyond the last gate are a deviation documented in acx.h
+    if (n_lists != c->hc.n_gates) return fail(ACX_ERR_ROOT_COUNT, "gateToGenQAP: one root list per gate is required");
+    for (uint64_t g = 0; g < n_lists; ++g)
+        if (counts[g] != c->hc.rows_of_gate(g)) return fail(ACX_ERR_ROOT_COUNT, "gateToGenQAP: wrong number of roots supplied");
     return ACX_OK;
 }
 
@@ -1141,8 +1171,7 @@ int acx_circuit_rows(const acx_circuit* c, const acx_fr* roots, uint64_t n_roots
     return ACX_OK;
 }
 
-int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_r1cs** out) {
-    if (!ctx || !c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+static int circuit_to_r1cs_impl(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_r1cs** out) {
     const HostCircuit& hc = c->hc;
     std::vector<uint64_t> order;
     ACX_TRY(root_order(hc, roots, n_roots, order));
@@ -1176,8 +1205,10 @@ int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots,
         for (size_t i = 0; i < hc.wires.size(); ++i) wflat[i] = (uint32_t)hc.flat(hc.wires[i]);
         // level-ordered records of the Mul gates (entry ranges of their A and B rows in the device CSR)
         std::vector<uint32_t> ptr_a(hc.n_rows() + 1), ptr_b(hc.n_rows() + 1);
-        HIP_TRY(hipMemcpy(ptr_a.data(), r->M[0].ptr, ptr_a.size() * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ptr_b.data(), r->M[1].ptr, ptr_b.size() * 4, hipMemcpyDeviceToHost));
+        // the plan is an optimisation: if anything below fails the system is still valid, only acx_r1cs_eval is not offered
+        if (hipMemcpy(ptr_a.data(), r->M[0].ptr, ptr_a.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(ptr_b.data(), r->M[1].ptr, ptr_b.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return ACX_OK;
         std::vector<uint32_t> mul(plan.items.size() * 4, 0xffffffffu);
         for (size_t t = 0; t < plan.items.size(); ++t) {
             const uint32_t g = plan.items[t];
@@ -1204,11 +1235,18 @@ int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots,
     return ACX_OK;
 }
 
+
+int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_r1cs** out) {
+    if (!ctx || !c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (c->field != ctx->field) return fail(ACX_ERR_INVALID_ARG, "circuit and context are over different fields");
+    return guarded([&]() -> int { return circuit_to_r1cs_impl(ctx, c, roots, n_roots, out); });
+}
+
 // ---------------------------------------------------------------------------------- R1CS
 int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C,
                   acx_r1cs** out) {
     const acx_csr* mats[3] = {A, B, C};
-    return r1cs_from_host(ctx, n, m, mats, out);
+    return guarded([&]() -> int { return r1cs_from_host(ctx, n, m, mats, out); });
 }
 
 void acx_r1cs_destroy(acx_r1cs* r) {

@@ -309,6 +309,11 @@ class Circuit:
         except Exception:
             pass
 
+    def check_root_counts(self, counts: Sequence[int]) -> None:
+        """One root list per gate, each of the gate's row count (src/QAP.hs:444-445,474): AcxError ROOT_COUNT otherwise."""
+        arr = np.ascontiguousarray(list(counts) or [0], dtype=np.uint32)
+        check(self.lib.acx_circuit_check_root_counts(self._h, _ptr(arr), len(counts)))
+
     def rows_per_gate(self) -> np.ndarray:
         out = np.zeros(max(self.n_gates, 1), dtype=np.uint32)
         check(self.lib.acx_circuit_rows_per_gate(self._h, _ptr(out)))

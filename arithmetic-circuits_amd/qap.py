@@ -124,16 +124,13 @@ class NaiveQAP(QAP):
         return fr_to_ints(coeffs[0, : int(lens[0])])
 
 
-def _roots_array(p: int, roots: Optional[Sequence[Sequence[int]]], rows_per_gate) -> Optional[np.ndarray]:
+def _roots_array(p: int, roots: Optional[Sequence[Sequence[int]]], circuit) -> Optional[np.ndarray]:
     if roots is None:
         return None
-    flat: List[int] = []
-    for g, rs in enumerate(roots):
-        if g < len(rows_per_gate) and len(rs) != int(rows_per_gate[g]):
-            # the reference panics here (src/QAP.hs:445,474); surface the same condition
-            from ._lib import AcxError, STATUS
-            raise AcxError(STATUS["ROOT_COUNT"], "gateToGenQAP: wrong number of roots supplied")
-        flat += [r % p for r in rs]
+    # the reference panics on a wrong per-gate count (src/QAP.hs:445,474); the C ABI validates the counts
+    # (acx_circuit_check_root_counts) and surfaces the same condition as ACX_ERR_ROOT_COUNT
+    circuit.check_root_counts([len(rs) for rs in roots])
+    flat: List[int] = [r % p for rs in roots for r in rs]
     return ints_to_fr(flat) if flat else np.zeros((0, 4), dtype=np.uint64)
 
 
@@ -142,7 +139,7 @@ def arithCircuitToGenQAP(ctx: Context, roots: Optional[Sequence[Sequence[int]]],
     if roots is not None and len(roots) < len(circuit.gates):
         circuit = ArithCircuit(circuit.gates[: len(roots)])   # zipWith truncates to the shorter list
     c = circuit.marshal(ctx.field)
-    r = c.to_r1cs(ctx, _roots_array(ctx.p, roots, c.rows_per_gate()))
+    r = c.to_r1cs(ctx, _roots_array(ctx.p, roots, c))
     return GenQAP(ctx, r, c.n_inputs, c.n_intermediates, c.n_outputs)
 
 

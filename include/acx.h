@@ -144,6 +144,13 @@ int acx_circuit_eval(const acx_circuit* c, const acx_fr* inputs, const uint8_t* 
  * (`addMissingZeroes` src/QAP.hs:566-576 is implicit). */
 int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots,
                         acx_r1cs** out);
+/* The reference takes roots as one list PER GATE (`[[k]]`, src/QAP.hs:530-539) and panics when a gate's list has
+ * the wrong length (src/QAP.hs:444-445,474).  A host that flattens the lists calls this first: counts[g] =
+ * length of gate g's list, n_lists = number of lists; ACX_ERR_ROOT_COUNT unless n_lists == #gates and every
+ * count equals the gate's row count.  Two deliberate deviations from the reference's corner cases:
+ * duplicate roots are an error here (ACX_ERR_DUPLICATE_ROOT) where `Map.fromList` would silently keep the
+ * last row, and surplus root lists are an error where `zipWith` + `addMissingZeroes` would append zero rows. */
+int acx_circuit_check_root_counts(const acx_circuit* c, const uint32_t* counts, uint64_t n_lists);
 /* The same rows on the host (pure host code), e.g. for a multi-GPU host that shards rows before
  * acx_r1cs_load.  Call acx_circuit_nnz first to size the buffers: rowptr[n_rows+1], col/val[nnz]. */
 int acx_circuit_nnz(const acx_circuit* c, uint64_t nnz[3]);

@@ -150,3 +150,89 @@ def test_empty_circuit(acx):
     assert (circ.n_rows, circ.m) == (0, 1)
     w, _ = circ.eval(np.zeros((0, 4), dtype=np.uint64))
     assert acx.fr_to_ints(w) == [1]
+
+
+def _gate_list(acx, kinds, tok_ofs, tok_op, tok_arg, scalars, aff_wires, wire_ofs, wires):
+    """Raw acx_gate_list from Python lists (keeps the arrays alive in the returned tuple)."""
+    u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+    u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
+    u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+    keep = (u8(kinds), u64(tok_ofs), u8(tok_op), u32(tok_arg), acx.ints_to_fr(scalars) if scalars else np.zeros((0, 4), np.uint64),
+            u32(aff_wires).reshape(-1, 2), u64(wire_ofs), u32(wires).reshape(-1, 2))
+    ptr = lambda a: a.ctypes.data if a.size else None
+    gl = acx._lib.GateList(len(kinds), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), ptr(keep[4]), keep[4].shape[0],
+                           ptr(keep[5]), keep[5].shape[0], ptr(keep[6]), ptr(keep[7]))
+    return gl, keep
+
+
+@pytest.mark.parametrize("shape", ["left", "right"])
+def test_deep_affine_chains_do_not_recurse(acx, shape):
+    """A Mul gate whose left side is a 200 000-term Add chain (the foldl / unsplit shape, src/Circuit/Arithmetic.hs:
+    238-244): marshalling, row construction and evaluation are iterative in libacx -- the reference handles such
+    trees and the drop-in must not overflow the C stack.  Row and value are checked in closed form."""
+    terms = 200_000
+    lib = acx._lib.load()
+    # pre-order tokens: left-nested  ADD^(t-1) v0 v1 ... v_{t-1}   /   right-nested  (ADD v_i)^(t-1) v_{t-1}
+    if shape == "left":
+        ops = [0] * (terms - 1) + [3] * terms
+        args = [0] * (terms - 1) + [i % 7 for i in range(terms)]
+    else:
+        ops, args = [], []
+        for i in range(terms - 1):
+            ops += [0, 3]
+            args += [0, i % 7]
+        ops.append(3)
+        args.append((terms - 1) % 7)
+    ops += [2]                     # right side: the constant 1
+    args += [0]
+    n_tok = len(ops)
+    gl, keep = _gate_list(acx, [0], [0, n_tok - 1, n_tok], ops, args, [1], [[0, i] for i in range(7)], [0, 1], [[2, 0]])
+    h = C.c_void_p()
+    acx._lib.check(lib.acx_circuit_create(0, C.byref(gl), C.byref(h)))
+    try:
+        nnz = (C.c_uint64 * 3)()
+        acx._lib.check(lib.acx_circuit_nnz(h, C.byref(nnz)))
+        assert list(nnz) == [7, 1, 1]
+        rowptr, col, val = np.zeros(2, np.uint32), np.zeros(7, np.uint32), np.zeros((7, 4), np.uint64)
+        acx._lib.check(lib.acx_circuit_rows(h, None, 0, 0, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data))
+        counts = [len(range(i, terms, 7)) for i in range(7)]
+        assert list(col) == list(range(1, 8)) and acx.fr_to_ints(val) == counts
+        inputs = acx.ints_to_fr([3, 5, 7, 11, 13, 17, 19])
+        w = np.zeros((9, 4), np.uint64)
+        acx._lib.check(lib.acx_circuit_eval(h, inputs.ctypes.data, None, 7, w.ctypes.data, None))
+        assert acx.fr_to_ints(w)[8] == sum(c * v for c, v in zip(counts, [3, 5, 7, 11, 13, 17, 19])) % P
+    finally:
+        lib.acx_circuit_destroy(h)
+
+
+def test_gate_list_null_arrays_and_malformed_streams(acx):
+    lib = acx._lib.load()
+    # the empty circuit with NULL arrays everywhere
+    gl = acx._lib.GateList(0, None, None, None, None, None, 0, None, 0, None, None)
+    h = C.c_void_p()
+    acx._lib.check(lib.acx_circuit_create(0, C.byref(gl), C.byref(h)))
+    dims = [C.c_uint64() for _ in range(5)]
+    acx._lib.check(lib.acx_circuit_dims(h, *[C.byref(d) for d in dims]))
+    assert [d.value for d in dims] == [0, 1, 0, 0, 0]
+    lib.acx_circuit_destroy(h)
+    # a nonzero count with a NULL array is an argument error, not a crash
+    gl2, keep = _gate_list(acx, [0], [0, 1, 2], [3, 3], [0, 0], [], [[0, 0]], [0, 1], [[2, 0]])
+    gl2.aff_wires = None
+    assert lib.acx_circuit_create(0, C.byref(gl2), C.byref(h)) == acx._lib.STATUS["INVALID_ARG"]
+    # truncated and over-long token streams
+    for ops in ([0, 3], [3, 3, 3], [0, 0, 3, 3]):
+        glb, keepb = _gate_list(acx, [0], [0, len(ops), len(ops) + 1], ops + [3], [0] * (len(ops) + 1), [], [[0, 0]], [0, 1], [[2, 0]])
+        assert lib.acx_circuit_create(0, C.byref(glb), C.byref(h)) == acx._lib.STATUS["BAD_CIRCUIT"], ops
+
+
+def test_root_count_validation_through_the_abi(acx):
+    """gateToGenQAP panics on a wrong per-gate root count (src/QAP.hs:444-445,474): ACX_ERR_ROOT_COUNT here."""
+    prog = acx.ArithCircuit([
+        acx.Mul(acx.Var(acx.InputWire(0)), acx.Var(acx.InputWire(1)), acx.IntermediateWire(0)),
+        acx.Equal(acx.IntermediateWire(0), acx.IntermediateWire(1), acx.OutputWire(0)),
+    ]).marshal()
+    prog.check_root_counts([1, 2])
+    for bad in ([2, 1], [1], [1, 2, 1], [3]):
+        with pytest.raises(acx.AcxError) as e:
+            prog.check_root_counts(bad)
+        assert e.value.status == acx._lib.STATUS["ROOT_COUNT"]
