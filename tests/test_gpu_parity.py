@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 FIELDS = {"bn254": R.BN254, "bls12_381": R.BLS12_381}
 
 
+def _need_gpu():
+    """Subprocess-based GPU tests have no context fixture: apply the fixtures' rule (tests/conftest.py)."""
+    import os, torch
+    if not torch.cuda.is_available() and os.environ.get("ACX_REQUIRE_GPU") != "1":
+        pytest.skip("no GPU visible (set ACX_REQUIRE_GPU=1 to make this an error)")
+
+
 def _ctx(request, field):
     return request.getfixturevalue("ctx_bn254" if field == "bn254" else "ctx_bls")
 
@@ -763,6 +770,7 @@ def test_bench_two_ranks_on_one_device():
     """The N > 1 path of bench.py (per-rank systems, half-ring verdict all-reduce, MAX-over-ranks timing,
     one JSON line from rank 0) with two ranks sharing cuda:0 over gloo: RCCL needs one GPU per rank, the
     control flow does not."""
+    _need_gpu()
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ACX_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
@@ -784,6 +792,7 @@ def test_bench_two_ranks_on_one_device():
 def test_sharded_layer_two_ranks_on_one_device():
     """ShardedR1CS and the four-step DistributedNTT with the HIP local kernels, world size 2, both ranks on
     cuda:0 over gloo (tests/dist_worker_gpu.py)."""
+    _need_gpu()
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
