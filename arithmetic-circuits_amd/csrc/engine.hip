@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -70,7 +71,25 @@ struct acx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     HostField hf;
-    std::mutex mu;
+    std::recursive_mutex mu;                               // caches + the device-pointer (single stream) path
+    // Host-buffer entry points (acx_r1cs_verify, acx_r1cs_residuals, acx_qap_h, acx_ntt, acx_qap_columns) block on
+    // the GPU; concurrent callers -- `safe` foreign calls from several Haskell capabilities -- each take a LANE:
+    // its own HIP stream, result slots and scratch arena, so their copies and kernels overlap.
+    struct Lane {
+        std::mutex mu;
+        hipStream_t stream = nullptr;
+        unsigned long long* d_result = nullptr;
+        uint32_t* d_err = nullptr;
+        void* arena = nullptr;
+        size_t arena_bytes = 0;
+        uint4* ntt_scratch = nullptr;
+        size_t ntt_scratch_bytes = 0;
+        hipStream_t copy_stream = nullptr;     // device-to-host copies that overlap the next batch's kernels
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    };
+    static constexpr int kLanes = 4;
+    Lane lanes[kLanes];
+    std::atomic<unsigned> lane_ticket{0};
     std::map<std::pair<uint32_t, int>, uint4*> twiddles;  // (log_m, inverse) -> omega_M^j, j < M
     std::map<std::pair<uint32_t, int>, uint4*> tw_low;    // (log_n, inverse) -> omega_N^j, j < 1024
     std::map<std::tuple<uint32_t, uint64_t, int, uint32_t>, uint4*> tw_scaled;   // (log_m, count, inverse, log_n of folded 1/N)
@@ -92,10 +111,35 @@ struct acx_ctx {
     int n_cu = 256;
 };
 
+using CtxLock = std::lock_guard<std::recursive_mutex>;
+
+// The lane the calling thread holds (host-buffer entry points), or null on the device-pointer path.
+static thread_local acx_ctx::Lane* t_lane = nullptr;
+static inline hipStream_t cur_stream(const acx_ctx* c) { return t_lane ? t_lane->stream : c->stream; }
+static inline unsigned long long* cur_result(const acx_ctx* c) { return t_lane ? t_lane->d_result : c->d_result; }
+static inline uint32_t* cur_err(const acx_ctx* c) { return t_lane ? t_lane->d_err : c->d_err; }
+
+struct LaneGuard {
+    acx_ctx::Lane* lane = nullptr;
+    explicit LaneGuard(acx_ctx* c) {
+        for (int i = 0; i < acx_ctx::kLanes && !lane; ++i)
+            if (c->lanes[i].mu.try_lock()) lane = &c->lanes[i];
+        if (!lane) {
+            lane = &c->lanes[c->lane_ticket.fetch_add(1) % acx_ctx::kLanes];
+            lane->mu.lock();
+        }
+        t_lane = lane;
+    }
+    ~LaneGuard() { t_lane = nullptr; lane->mu.unlock(); }
+    LaneGuard(const LaneGuard&) = delete;
+    LaneGuard& operator=(const LaneGuard&) = delete;
+};
+
 struct DevMatrix {
     u32* ptr = nullptr;   // rowptr (CSR) or colptr (CSC)
     u32* idx = nullptr;   // col (CSR) or row (CSC)
     uint4* val = nullptr; // dev format
+    u32* colid = nullptr; // CSC only: column of every entry
     uint64_t nnz = 0;
 };
 
@@ -188,13 +232,31 @@ inline uint32_t ceil_log2(uint64_t n) {
         else { using F = Bls12381Fr; __VA_ARGS__; }       \
     } while (0)
 
+// Scratch of the calling thread's lane, grown on demand (hipMalloc / hipFree synchronise the whole device, so the
+// steady state must not allocate).  One reservation per entry-point call; carve it with the returned base.
+int lane_reserve(acx_ctx* c, size_t bytes, uint8_t** base) {
+    acx_ctx::Lane* ln = t_lane;
+    if (!ln) return fail(ACX_ERR_INVALID_ARG, "internal: no lane");
+    if (ln->arena_bytes < bytes) {
+        HIP_TRY(hipStreamSynchronize(ln->stream));
+        if (ln->arena) (void)hipFree(ln->arena);
+        ln->arena = nullptr; ln->arena_bytes = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        HIP_TRY(hipMalloc(&ln->arena, want));
+        ln->arena_bytes = want;
+    }
+    *base = static_cast<uint8_t*>(ln->arena);
+    return ACX_OK;
+}
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 int launch_convert(acx_ctx* c, bool to_dev, const void* in, void* out, uint64_t count, uint32_t* d_err) {
     if (count == 0) return ACX_OK;
     const int grid = grid_for(c, count);
     DISPATCH_FIELD(c, {
-        if (to_dev) hipLaunchKernelGGL((k_convert<F, true>), dim3(grid), dim3(kBlock), 0, c->stream,
+        if (to_dev) hipLaunchKernelGGL((k_convert<F, true>), dim3(grid), dim3(kBlock), 0, cur_stream(c),
                                        (const uint4*)in, (uint4*)out, count, d_err);
-        else hipLaunchKernelGGL((k_convert<F, false>), dim3(grid), dim3(kBlock), 0, c->stream,
+        else hipLaunchKernelGGL((k_convert<F, false>), dim3(grid), dim3(kBlock), 0, cur_stream(c),
                                 (const uint4*)in, (uint4*)out, count, d_err);
     });
     HIP_TRY(hipGetLastError());
@@ -204,12 +266,12 @@ int launch_convert(acx_ctx* c, bool to_dev, const void* in, void* out, uint64_t 
 // Upload canonical host elements and convert to dev format in place; checks canonicity.
 int upload_elements(acx_ctx* c, const acx_fr* host, uint64_t count, uint4* d_out) {
     if (count == 0) return ACX_OK;
-    HIP_TRY(hipMemsetAsync(c->d_err, 0, 4, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_out, host, count * 32, hipMemcpyHostToDevice, c->stream));
-    ACX_TRY(launch_convert(c, true, d_out, d_out, count, c->d_err));
+    HIP_TRY(hipMemsetAsync(cur_err(c), 0, 4, cur_stream(c)));
+    HIP_TRY(hipMemcpyAsync(d_out, host, count * 32, hipMemcpyHostToDevice, cur_stream(c)));
+    ACX_TRY(launch_convert(c, true, d_out, d_out, count, cur_err(c)));
     uint32_t err = 0;
-    HIP_TRY(hipMemcpyAsync(&err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(&err, cur_err(c), 4, hipMemcpyDeviceToHost, cur_stream(c)));
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     if (err) return fail(ACX_ERR_NONCANONICAL, "element >= p");
     return ACX_OK;
 }
@@ -217,13 +279,14 @@ int upload_elements(acx_ctx* c, const acx_fr* host, uint64_t count, uint4* d_out
 int download_elements(acx_ctx* c, const uint4* d_in, uint64_t count, acx_fr* host, uint4* d_scratch) {
     if (count == 0) return ACX_OK;
     ACX_TRY(launch_convert(c, false, d_in, d_scratch, count, nullptr));
-    HIP_TRY(hipMemcpyAsync(host, d_scratch, count * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(host, d_scratch, count * 32, hipMemcpyDeviceToHost, cur_stream(c)));
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     return ACX_OK;
 }
 
 // omega_M^j for j < M = 2^log_m (inverse: omega_M^-j), cached.  Caller holds ctx->mu.
 int get_pow_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
+    CtxLock lock(c->mu);
     auto key = std::make_pair(log_m, inverse);
     auto it = c->twiddles.find(key);
     if (it != c->twiddles.end()) { *out = it->second; return ACX_OK; }
@@ -232,9 +295,10 @@ int get_pow_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
     HIP_TRY(hipMalloc((void**)&tw, count * 32));
     H256 w = c->hf.root_of_unity((int)log_m);
     if (inverse) w = c->hf.inv(w);
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, tw,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, cur_stream(c), tw,
                                          count, dev_arg(c->hf, w)));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));   // other lanes may use the table from their own streams
     c->twiddles[key] = tw;
     *out = tw;
     return ACX_OK;
@@ -242,6 +306,7 @@ int get_pow_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
 
 // omega_N^j for j < 1024 (low level of the two-level twiddle table), cached.
 int get_low_table(acx_ctx* c, uint32_t log_n, int inverse, uint4** out) {
+    CtxLock lock(c->mu);
     auto key = std::make_pair(log_n, inverse);
     auto it = c->tw_low.find(key);
     if (it != c->tw_low.end()) { *out = it->second; return ACX_OK; }
@@ -249,9 +314,10 @@ int get_low_table(acx_ctx* c, uint32_t log_n, int inverse, uint4** out) {
     HIP_TRY(hipMalloc((void**)&tw, 1024 * 32));
     H256 w = c->hf.root_of_unity((int)log_n);
     if (inverse) w = c->hf.inv(w);
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(4), dim3(kBlock), 0, c->stream, tw, (u64)1024,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(4), dim3(kBlock), 0, cur_stream(c), tw, (u64)1024,
                                          dev_arg(c->hf, w)));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));   // other lanes may use the table from their own streams
     c->tw_low[key] = tw;
     *out = tw;
     return ACX_OK;
@@ -259,6 +325,7 @@ int get_low_table(acx_ctx* c, uint32_t log_n, int inverse, uint4** out) {
 
 // omega_M^j for j < M/2 in limb form (sub-transform twiddles of k_ntt_r4), cached.
 int get_limb_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
+    CtxLock lock(c->mu);
     auto key = std::make_pair(log_m, inverse);
     auto it = c->tw_limbs.find(key);
     if (it != c->tw_limbs.end()) { *out = it->second; return ACX_OK; }
@@ -267,9 +334,10 @@ int get_limb_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
     HIP_TRY(hipMalloc((void**)&tw, count * 48));
     H256 w = c->hf.root_of_unity((int)log_m);
     if (inverse) w = c->hf.inv(w);
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_limbs<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, tw,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_limbs<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, cur_stream(c), tw,
                                          count, dev_arg(c->hf, w)));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));   // other lanes may use the table from their own streams
     c->tw_limbs[key] = tw;
     *out = tw;
     return ACX_OK;
@@ -277,6 +345,7 @@ int get_limb_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
 
 // first * omega_M^j for j < count (M = 2^log_m; omega^-1 when inverse); first = 1 or 1/2^scaled_log_n.  Cached.
 int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, uint32_t scaled_log_n, uint4** out) {
+    CtxLock lock(c->mu);
     if (scaled_log_n == 0 && count == (1ull << log_m)) return get_pow_table(c, log_m, inverse, out);
     if (scaled_log_n == 0 && count == 1024) return get_low_table(c, log_m, inverse, out);
     const auto key = std::make_tuple(log_m, count, inverse, scaled_log_n);
@@ -287,9 +356,10 @@ int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, ui
     H256 w = c->hf.root_of_unity((int)log_m);
     if (inverse) w = c->hf.inv(w);
     const H256 first = c->hf.inv(c->hf.from_u64(1ull << scaled_log_n));
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, tw,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, cur_stream(c), tw,
                                          count, dev_arg(c->hf, w), dev_arg(c->hf, first)));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));   // other lanes may use the table from their own streams
     c->tw_scaled[key] = tw;
     *out = tw;
     return ACX_OK;
@@ -299,6 +369,7 @@ int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, ui
 // between g (forward) and 1/g with 1/N folded in (inverse) on every call.
 // scaled: the low table carries the factor 1/2^log_n (closing multiplication of an inverse coset transform).
 int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scaled, uint4** lo, uint4** hi) {
+    CtxLock lock(c->mu);
     for (auto& e : c->cosets)
         if (e.lo && e.base == base_mont && e.log_n == log_n && e.scaled == scaled) {
             e.stamp = ++c->coset_clock;
@@ -309,7 +380,7 @@ int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scal
     acx_ctx::CosetTables* slot = &c->cosets[0];
     for (auto& e : c->cosets) if (!e.lo || e.stamp < slot->stamp) { slot = &e; if (!e.lo) break; }
     if (slot->lo) {
-        HIP_TRY(hipStreamSynchronize(c->stream));   // previous users of the old tables are done
+        HIP_TRY(hipDeviceSynchronize());           // previous users of the old tables (on any lane) are done
         (void)hipFree(slot->lo);
         if (slot->hi) (void)hipFree(slot->hi);
         slot->lo = slot->hi = nullptr;
@@ -317,15 +388,16 @@ int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scal
     const uint64_t hi_count = log_n > 10 ? (1ull << (log_n - 10)) : 0;
     HIP_TRY(hipMalloc((void**)&slot->lo, 1024 * 32));
     const H256 first = scaled ? c->hf.inv(c->hf.from_u64(1ull << log_n)) : c->hf.one();
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(4), dim3(kBlock), 0, c->stream, slot->lo,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(4), dim3(kBlock), 0, cur_stream(c), slot->lo,
                                          (u64)1024, dev_arg(c->hf, base_mont), dev_arg(c->hf, first)));
     if (hi_count) {
         HIP_TRY(hipMalloc((void**)&slot->hi, hi_count * 32));
         const H256 b1024 = c->hf.pow_u64(base_mont, 1024);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, hi_count)), dim3(kBlock), 0, c->stream,
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, hi_count)), dim3(kBlock), 0, cur_stream(c),
                                              slot->hi, hi_count, dev_arg(c->hf, b1024)));
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     slot->base = base_mont; slot->log_n = log_n; slot->scaled = scaled; slot->stamp = ++c->coset_clock;
     *lo = slot->lo;
     *hi = slot->hi;
@@ -429,14 +501,16 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
     uint4* scratch = nullptr;
     if (P > 1) {
         const size_t need = (size_t)batch * N * 32;
-        if (c->ntt_scratch_bytes < need) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
-            c->ntt_scratch = nullptr; c->ntt_scratch_bytes = 0;
-            HIP_TRY(hipMalloc((void**)&c->ntt_scratch, need));
-            c->ntt_scratch_bytes = need;
+        uint4*& buf = t_lane ? t_lane->ntt_scratch : c->ntt_scratch;        // ping-pong buffer of this stream
+        size_t& have = t_lane ? t_lane->ntt_scratch_bytes : c->ntt_scratch_bytes;
+        if (have < need) {
+            HIP_TRY(hipStreamSynchronize(cur_stream(c)));
+            if (buf) (void)hipFree(buf);
+            buf = nullptr; have = 0;
+            HIP_TRY(hipMalloc((void**)&buf, need));
+            have = need;
         }
-        scratch = c->ntt_scratch;
+        scratch = buf;
     }
     uint4 *sc_lo = nullptr, *sc_hi = nullptr;
     if (shift_mont) {
@@ -544,12 +618,12 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         if (r4) {
             bool ok = false;
             DISPATCH_FIELD(c, {
-                ok = cfg.xchg == 1 ? launch_r4<F, kXchgDpp>(lp, lgrp, (unsigned)tiles, c->stream, Q)
-                                   : launch_r4<F, kXchgLds>(lp, lgrp, (unsigned)tiles, c->stream, Q);
+                ok = cfg.xchg == 1 ? launch_r4<F, kXchgDpp>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q)
+                                   : launch_r4<F, kXchgLds>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
             });
             if (!ok) return fail(ACX_ERR_UNSUPPORTED, "NTT plan: kernel instance missing");
         } else {
-            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_tile<F>), dim3((unsigned)tiles), dim3(kBlock), 0, c->stream, Q));
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_tile<F>), dim3((unsigned)tiles), dim3(kBlock), 0, cur_stream(c), Q));
         }
     }
     HIP_TRY(hipGetLastError());
@@ -649,8 +723,8 @@ int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t wo
     const uint64_t tiles = cols / T;
     bool ok = false;
     DISPATCH_FIELD(c, {
-        ok = cfg.xchg == 1 ? launch_r4<F, kXchgDpp>(lp, lgrp, (unsigned)tiles, c->stream, Q)
-                           : launch_r4<F, kXchgLds>(lp, lgrp, (unsigned)tiles, c->stream, Q);
+        ok = cfg.xchg == 1 ? launch_r4<F, kXchgDpp>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q)
+                           : launch_r4<F, kXchgLds>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
     });
     if (!ok) return fail(ACX_ERR_UNSUPPORTED, "distributed NTT step: kernel instance missing");
     HIP_TRY(hipGetLastError());
@@ -683,9 +757,9 @@ int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out) {
         C{r->M[2].ptr, r->M[2].idx, r->M[2].val};
     const int grid = (int)((r->n_long + kBlock - 1) / kBlock);
     DISPATCH_FIELD(c, {
-        if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual_rows<F, true>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
+        if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual_rows<F, true>), dim3(grid), dim3(kBlock), 0, cur_stream(c), A, B, C,
                                           d_w, (const u32*)r->long_rows, r->n_long, out);
-        else hipLaunchKernelGGL((k_r1cs_residual_rows<F, false>), dim3(grid), dim3(kBlock), 0, c->stream, A, B, C,
+        else hipLaunchKernelGGL((k_r1cs_residual_rows<F, false>), dim3(grid), dim3(kBlock), 0, cur_stream(c), A, B, C,
                                 d_w, (const u32*)r->long_rows, r->n_long, out);
     });
     HIP_TRY(hipGetLastError());
@@ -699,7 +773,7 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
     const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset};
     const SellSystem S = sell_system(r, d_w, out);
     const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, c->stream,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, cur_stream(c),
                                          (const SellSystem*)nullptr, S));
     HIP_TRY(hipGetLastError());
     return launch_long_rows(r, d_w, out);
@@ -731,11 +805,11 @@ int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
         for (uint64_t i = ws; i < we; ++i) perm[i] = key[idx[i - ws]] == 0xffffffffu ? kNoRow : idx[i - ws];
     }
     HIP_TRY(hipMalloc((void**)&r->perm, perm.size() * 4));
-    HIP_TRY(hipMemcpyAsync(r->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(r->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
     r->n_long = (uint32_t)longs.size();
     if (!longs.empty()) {
         HIP_TRY(hipMalloc((void**)&r->long_rows, longs.size() * 4));
-        HIP_TRY(hipMemcpyAsync(r->long_rows, longs.data(), longs.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(r->long_rows, longs.data(), longs.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
     }
     std::vector<uint32_t> ofs(n_slices + 1);
     for (int k = 0; k < 3; ++k) {
@@ -752,14 +826,14 @@ int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
         HIP_TRY(hipMalloc((void**)&r->sell_ofs[k], ofs.size() * 4));
         HIP_TRY(hipMalloc((void**)&r->sell_tail[k], std::max<uint64_t>(slots, 1) * kSlice * 8));
         HIP_TRY(hipMalloc((void**)&r->sell_val[k], std::max<uint64_t>(slots, 1) * kSlice * 32));
-        HIP_TRY(hipMemcpyAsync(r->sell_ofs[k], ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));   // ofs is reused by the next matrix
+        HIP_TRY(hipMemcpyAsync(r->sell_ofs[k], ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
+        HIP_TRY(hipStreamSynchronize(cur_stream(c)));   // ofs is reused by the next matrix
         const CsrDev M{r->M[k].ptr, r->M[k].idx, r->M[k].val};
-        hipLaunchKernelGGL(k_build_sell, dim3((n_slices + 3) / 4), dim3(kBlock), 0, c->stream, M, (const u32*)r->perm,
+        hipLaunchKernelGGL(k_build_sell, dim3((n_slices + 3) / 4), dim3(kBlock), 0, cur_stream(c), M, (const u32*)r->perm,
                            (const u32*)r->sell_ofs[k], n_slices, r->sell_tail[k], r->sell_val[k]);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     return ACX_OK;
 }
 
@@ -830,13 +904,13 @@ int upload_matrix(acx_ctx* c, const std::vector<uint32_t>& ptr, const std::vecto
     HIP_TRY(hipMalloc((void**)&out.ptr, ptr.size() * 4));
     HIP_TRY(hipMalloc((void**)&out.idx, std::max<size_t>(idx.size(), 1) * 4));
     HIP_TRY(hipMalloc((void**)&out.val, std::max<size_t>(idx.size(), 1) * 32));
-    HIP_TRY(hipMemcpyAsync(out.ptr, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, c->stream));
-    if (!idx.empty()) HIP_TRY(hipMemcpyAsync(out.idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(out.ptr, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
+    if (!idx.empty()) HIP_TRY(hipMemcpyAsync(out.idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
     if (convert) {
         ACX_TRY(upload_elements(c, val, idx.size(), out.val));
     } else {
-        if (!idx.empty()) HIP_TRY(hipMemcpyAsync(out.val, val, idx.size() * 32, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!idx.empty()) HIP_TRY(hipMemcpyAsync(out.val, val, idx.size() * 32, hipMemcpyHostToDevice, cur_stream(c)));
+        HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     }
     return ACX_OK;
 }
@@ -845,6 +919,7 @@ void free_matrix(DevMatrix& mtx) {
     if (mtx.ptr) (void)hipFree(mtx.ptr);
     if (mtx.idx) (void)hipFree(mtx.idx);
     if (mtx.val) (void)hipFree(mtx.val);
+    if (mtx.colid) (void)hipFree(mtx.colid);
     mtx = DevMatrix{};
 }
 
@@ -876,7 +951,7 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
     if (m == 0 || m >= 0xffffffffull || n >= 0xffffffffull) return fail(ACX_ERR_TOO_LARGE, "n or m out of range");
     const uint32_t log_n = ceil_log2(std::max<uint64_t>(n, 1));
     if ((int)log_n > ctx->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "n exceeds 2^two_adicity");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    CtxLock lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     acx_r1cs* r = new (std::nothrow) acx_r1cs();
     if (!r) return fail(ACX_ERR_OOM, "host allocation failed");
@@ -914,32 +989,53 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
     return ACX_OK;
 }
 
-// Build the CSC copies (device) from the device CSR.  Caller holds ctx->mu.
+// Build the CSC copies on the device from the device CSR: histogram, scan, fill (kernels.hip.h K6).
 int ensure_csc(acx_r1cs* r) {
-    if (r->has_csc) return ACX_OK;
     acx_ctx* c = r->ctx;
+    CtxLock lock(c->mu);
+    if (r->has_csc) return ACX_OK;
+    const hipStream_t st = cur_stream(c);
     for (int k = 0; k < 3; ++k) {
-        const uint64_t nnz = r->M[k].nnz;
-        std::vector<uint32_t> rowptr(r->n + 1), col(nnz);
-        std::vector<acx_fr> val(nnz), tval(nnz);
-        HIP_TRY(hipMemcpy(rowptr.data(), r->M[k].ptr, (r->n + 1) * 4, hipMemcpyDeviceToHost));
-        if (nnz) {
-            HIP_TRY(hipMemcpy(col.data(), r->M[k].idx, nnz * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(val.data(), r->M[k].val, nnz * 32, hipMemcpyDeviceToHost));  // raw dev format
+        const DevMatrix& M = r->M[k];
+        DevMatrix& T = r->T[k];
+        T.nnz = M.nnz;
+        DevBuf count, cursor;
+        ACX_TRY(count.alloc((r->m + 1) * 4));
+        ACX_TRY(cursor.alloc((r->m + 1) * 4));
+        HIP_TRY(hipMalloc((void**)&T.ptr, (r->m + 1) * 4));
+        HIP_TRY(hipMalloc((void**)&T.idx, std::max<uint64_t>(M.nnz, 1) * 4));
+        HIP_TRY(hipMalloc((void**)&T.colid, std::max<uint64_t>(M.nnz, 1) * 4));
+        HIP_TRY(hipMalloc((void**)&T.val, std::max<uint64_t>(M.nnz, 1) * 32));
+        HIP_TRY(hipMemsetAsync(count.p, 0, (r->m + 1) * 4, st));
+        HIP_TRY(hipMemsetAsync(cursor.p, 0, (r->m + 1) * 4, st));
+        if (M.nnz) hipLaunchKernelGGL(k_col_histogram, dim3(grid_for(c, M.nnz)), dim3(kBlock), 0, st, (const u32*)M.idx, M.nnz, count.as<u32>());
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const u32*)count.as<u32>(), T.ptr, r->m);
+        if (M.nnz) {
+            const CsrDev csr{M.ptr, M.idx, M.val};
+            hipLaunchKernelGGL(k_csc_fill, dim3(grid_for(c, r->n)), dim3(kBlock), 0, st, csr, r->n, (const u32*)T.ptr, cursor.as<u32>(),
+                               T.idx, T.colid, T.val);
         }
-        std::vector<uint32_t> colptr(r->m + 1, 0), rowidx(nnz);
-        for (uint64_t e = 0; e < nnz; ++e) ++colptr[col[e] + 1];
-        for (uint64_t j = 0; j < r->m; ++j) colptr[j + 1] += colptr[j];
-        std::vector<uint32_t> cursor(colptr.begin(), colptr.end() - 1);
-        for (uint64_t i = 0; i < r->n; ++i)
-            for (uint32_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-                const uint32_t dst = cursor[col[e]]++;
-                rowidx[dst] = (uint32_t)i;
-                tval[dst] = val[e];
-            }
-        ACX_TRY(upload_matrix(c, colptr, rowidx, tval.data(), false, r->T[k]));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));       // count / cursor go out of scope; other lanes may use the CSC from here on
     }
     r->has_csc = true;
+    return ACX_OK;
+}
+
+// createPolynomialsFFT for wires [wire_begin, wire_begin + cnt) of one matrix, on the calling thread's stream:
+// d_out (cnt * N dev elements) receives the coefficients, d_len (cnt) the stripped lengths.
+int qap_columns_core(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t cnt, uint4* d_out, unsigned long long* d_len) {
+    acx_ctx* c = r->ctx;
+    const uint64_t N = 1ull << r->log_n;
+    const DevMatrix& T = r->T[matrix];
+    if (cnt == 0) return ACX_OK;
+    HIP_TRY(hipMemsetAsync(d_out, 0, cnt * N * 32, cur_stream(c)));
+    if (T.nnz)
+        hipLaunchKernelGGL(k_scatter_columns, dim3(grid_for(c, T.nnz / 4 + 1)), dim3(kBlock), 0, cur_stream(c), (const u32*)T.ptr, (const u32*)T.idx,
+                           (const u32*)T.colid, (const uint4*)T.val, wire_begin, cnt, r->log_n, d_out);
+    ACX_TRY(ntt_dev_locked(c, d_out, r->log_n, cnt, 1, nullptr));
+    if (d_len) DISPATCH_FIELD(c, hipLaunchKernelGGL((k_poly_len<F>), dim3((unsigned)cnt), dim3(kBlock), 0, cur_stream(c), (const uint4*)d_out, r->log_n, d_len));
+    HIP_TRY(hipGetLastError());
     return ACX_OK;
 }
 
@@ -988,8 +1084,12 @@ int acx_ctx_create(int field, int device_id, acx_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->hf = field == ACX_FIELD_BN254_FR ? HostField::make<Bn254Fr>() : HostField::make<Bls12381Fr>();
     c->ntt = ntt_cfg_from_env();
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&c->d_result, 16) != hipSuccess || hipMalloc((void**)&c->d_err, 4) != hipSuccess) {
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&c->d_result, 16) == hipSuccess && hipMalloc((void**)&c->d_err, 4) == hipSuccess;
+    for (auto& ln : c->lanes)
+        ok = ok && hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess &&
+             hipMalloc((void**)&ln.d_result, 16) == hipSuccess && hipMalloc((void**)&ln.d_err, 4) == hipSuccess;
+    if (!ok) {
         acx_ctx_destroy(c);
         return fail(ACX_ERR_HIP, "context resource creation failed");
     }
@@ -1000,7 +1100,7 @@ int acx_ctx_create(int field, int device_id, acx_ctx** out) {
 void acx_ctx_destroy(acx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto& kv : c->tw_low) (void)hipFree(kv.second);
     for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
@@ -1010,12 +1110,21 @@ void acx_ctx_destroy(acx_ctx* c) {
     if (c->d_result) (void)hipFree(c->d_result);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (auto& ln : c->lanes) {
+        if (ln.d_result) (void)hipFree(ln.d_result);
+        if (ln.d_err) (void)hipFree(ln.d_err);
+        if (ln.arena) (void)hipFree(ln.arena);
+        if (ln.ntt_scratch) (void)hipFree(ln.ntt_scratch);
+        for (auto& e : ln.ev) if (e) (void)hipEventDestroy(e);
+        if (ln.copy_stream) (void)hipStreamDestroy(ln.copy_stream);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
     delete c;
 }
 
 int acx_ctx_set_root(acx_ctx* c, uint32_t two_adicity, const acx_fr* omega) {
     if (!c || !omega || two_adicity == 0 || two_adicity > 64) return fail(ACX_ERR_INVALID_ARG, "bad argument");
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     H256 w;
     ACX_TRY(read_h256(omega, c->hf, w));
     // must have exact order 2^two_adicity: w^(2^(s-1)) == -1
@@ -1023,7 +1132,7 @@ int acx_ctx_set_root(acx_ctx* c, uint32_t two_adicity, const acx_fr* omega) {
     for (uint32_t i = 0; i + 1 < two_adicity; ++i) t = c->hf.mul(t, t);
     if (t != c->hf.neg(c->hf.one())) return fail(ACX_ERR_INVALID_ARG, "omega is not a primitive 2^s-th root of unity");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());                       // nothing in flight may still read the old tables
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto& kv : c->tw_low) (void)hipFree(kv.second);
     for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
@@ -1047,6 +1156,7 @@ int acx_ctx_sync(acx_ctx* c) {
     if (!c) return fail(ACX_ERR_INVALID_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& ln : c->lanes) HIP_TRY(hipStreamSynchronize(ln.stream));
     return ACX_OK;
 }
 
@@ -1188,7 +1298,7 @@ static int circuit_to_r1cs_impl(acx_ctx* ctx, const acx_circuit* c, const acx_fr
     HostCircuit::EvalPlan plan;
     if (hc.n_gates > 0 && hc.n_gates < 0xffffffffull && hc.build_plan(plan)) {
         acx_r1cs* r = *out;
-        std::lock_guard<std::mutex> lock(ctx->mu);
+        CtxLock lock(ctx->mu);
         const uint64_t ng = hc.n_gates;
         std::vector<uint32_t> inv(hc.n_rows());
         if (order.empty()) for (uint64_t i = 0; i < inv.size(); ++i) inv[i] = (uint32_t)i;
@@ -1252,9 +1362,9 @@ int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const 
 void acx_r1cs_destroy(acx_r1cs* r) {
     if (!r) return;
     {
-        std::lock_guard<std::mutex> lock(r->ctx->mu);
+        CtxLock lock(r->ctx->mu);
         (void)hipSetDevice(r->ctx->device);
-        (void)hipStreamSynchronize(r->ctx->stream);
+        (void)hipDeviceSynchronize();        // every lane: nothing may still be using this object
         free_r1cs_device(r);
     }
     delete r;
@@ -1272,7 +1382,7 @@ int acx_r1cs_dims(const acx_r1cs* r, uint64_t* n, uint64_t* m, uint32_t* log_n, 
 int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* col, acx_fr* val) {
     if (!r || matrix < 0 || matrix > 2 || !rowptr) return fail(ACX_ERR_INVALID_ARG, "bad argument");
     acx_ctx* c = r->ctx;
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     const DevMatrix& M = r->M[matrix];
     HIP_TRY(hipMemcpy(rowptr, M.ptr, (r->n + 1) * 4, hipMemcpyDeviceToHost));
@@ -1285,16 +1395,16 @@ int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* c
     return ACX_OK;
 }
 
-static int verify_common(acx_r1cs* r, const acx_fr* witness, uint64_t* n_bad, uint64_t* first_bad, uint4* d_res,
+static int verify_common(acx_r1cs* r, const acx_fr* witness, uint4* d_w, uint64_t* n_bad, uint64_t* first_bad, uint4* d_res,
                          uint4* d_dots, uint64_t dots_stride) {
     acx_ctx* c = r->ctx;
-    ACX_TRY(upload_elements(c, witness, r->m, r->d_w));
+    ACX_TRY(upload_elements(c, witness, r->m, d_w));
     const unsigned long long init[2] = {0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(c->d_result, init, 16, hipMemcpyHostToDevice, c->stream));
-    ACX_TRY(launch_residual(r, r->d_w, 0, c->d_result, d_res, d_dots, dots_stride));
+    HIP_TRY(hipMemcpyAsync(cur_result(c), init, 16, hipMemcpyHostToDevice, cur_stream(c)));
+    ACX_TRY(launch_residual(r, d_w, 0, cur_result(c), d_res, d_dots, dots_stride));
     unsigned long long res[2];
-    HIP_TRY(hipMemcpyAsync(res, c->d_result, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(res, cur_result(c), 16, hipMemcpyDeviceToHost, cur_stream(c)));
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     if (n_bad) *n_bad = res[0];
     if (first_bad) *first_bad = res[1];
     return ACX_OK;
@@ -1302,10 +1412,12 @@ static int verify_common(acx_r1cs* r, const acx_fr* witness, uint64_t* n_bad, ui
 
 int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
     if (!r || !witness || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lock(r->ctx->mu);
+    LaneGuard lane(r->ctx);                                  // concurrent callers overlap: one stream + scratch per lane
     HIP_TRY(hipSetDevice(r->ctx->device));
+    uint8_t* base = nullptr;
+    ACX_TRY(lane_reserve(r->ctx, r->m * 32, &base));
     uint64_t bad = 0, first = ~0ull;
-    ACX_TRY(verify_common(r, witness, &bad, &first, nullptr, nullptr, 0));
+    ACX_TRY(verify_common(r, witness, (uint4*)base, &bad, &first, nullptr, nullptr, 0));
     *ok = bad == 0;
     if (n_bad) *n_bad = bad;
     if (first_bad) *first_bad = first;
@@ -1319,7 +1431,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
         return fail(ACX_ERR_UNSUPPORTED, "no device evaluation plan (system not built from a single-assignment circuit)");
     acx_ctx* c = r->ctx;
     const HostField& hf = c->hf;
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     // which wires hold a value afterwards (what the QapSet would contain)
     std::vector<uint8_t> as(r->plan_written);
@@ -1333,7 +1445,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     std::memset(w0.data(), 0, w0.size() * 32);
     w0[0].b[0] = 1;
     for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) w0[1 + i] = inputs[i];
-    HIP_TRY(hipMemsetAsync(r->d_w, 0, r->m * 32, c->stream));
+    HIP_TRY(hipMemsetAsync(r->d_w, 0, r->m * 32, cur_stream(c)));
     ACX_TRY(upload_elements(c, w0.data(), w0.size(), r->d_w));
     Exp256 pm2;
     {
@@ -1347,7 +1459,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
         const uint32_t lo = r->plan_level_ofs[l], cnt = r->plan_level_ofs[l + 1] - lo;
         if (cnt == 0) continue;
         const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo};
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level<F>), dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level<F>), dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, cur_stream(c),
                                              G, A, B, r->d_w, pm2));
     }
     HIP_TRY(hipGetLastError());
@@ -1356,7 +1468,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
         ACX_TRY(tmp.alloc(r->m * 32));
         ACX_TRY(download_elements(c, r->d_w, r->m, witness, tmp.as<uint4>()));
     } else {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     }
     if (assigned) std::memcpy(assigned, as.data(), as.size());
     return ACX_OK;
@@ -1365,14 +1477,14 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
 int acx_r1cs_verify_resident(acx_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
     if (!r || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     const unsigned long long init[2] = {0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(c->d_result, init, 16, hipMemcpyHostToDevice, c->stream));
-    ACX_TRY(launch_residual(r, r->d_w, 0, c->d_result, nullptr, nullptr, 0));
+    HIP_TRY(hipMemcpyAsync(cur_result(c), init, 16, hipMemcpyHostToDevice, cur_stream(c)));
+    ACX_TRY(launch_residual(r, r->d_w, 0, cur_result(c), nullptr, nullptr, 0));
     unsigned long long res[2];
-    HIP_TRY(hipMemcpyAsync(res, c->d_result, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(res, cur_result(c), 16, hipMemcpyDeviceToHost, cur_stream(c)));
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     *ok = res[0] == 0;
     if (n_bad) *n_bad = res[0];
     if (first_bad) *first_bad = res[1];
@@ -1382,35 +1494,36 @@ int acx_r1cs_verify_resident(acx_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* fi
 int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out) {
     if (!r || !witness || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
-    std::lock_guard<std::mutex> lock(c->mu);
+    LaneGuard lane(c);
     HIP_TRY(hipSetDevice(c->device));
-    DevBuf res;
-    ACX_TRY(res.alloc(r->n * 32));
-    ACX_TRY(verify_common(r, witness, nullptr, nullptr, res.as<uint4>(), nullptr, 0));
-    return download_elements(c, res.as<uint4>(), r->n, out, res.as<uint4>());
+    uint8_t* base = nullptr;
+    const size_t wb = align256(r->m * 32);
+    ACX_TRY(lane_reserve(c, wb + r->n * 32, &base));
+    uint4* res = (uint4*)(base + wb);
+    ACX_TRY(verify_common(r, witness, (uint4*)base, nullptr, nullptr, res, nullptr, 0));
+    return download_elements(c, res, r->n, out, res);
 }
 
 // verificationWitnessZk on device-resident data (caller holds ctx->mu): residual dots -> 3 iNTT -> 3 coset NTT ->
 // pointwise -> coset iNTT (+ the zero-knowledge terms).  d_h receives N+1 dev elements, not stripped.
-static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4* d_h, unsigned long long* d_result) {
+static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4* d_h, unsigned long long* d_result,
+                            uint4* d /* 5N elements of scratch */) {
     acx_ctx* c = r->ctx;
     const HostField& hf = c->hf;
     if ((int)r->log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
     const uint64_t N = 1ull << r->log_n;
-    if (!r->qh) HIP_TRY(hipMalloc((void**)&r->qh, 5 * N * 32));      // dots (3N) + kept L0, R0 (2N): lives with the system
-    uint4* d = r->qh;
-    uint4* keep = d + 6 * N;
-    HIP_TRY(hipMemsetAsync(d, 0, 3 * N * 32, c->stream));  // rows n..N-1 are the zero padding
+    uint4* keep = d + 6 * N;                                          // dots (3N) + kept L0, R0 (2N)
+    HIP_TRY(hipMemsetAsync(d, 0, 3 * N * 32, cur_stream(c)));  // rows n..N-1 are the zero padding
     ACX_TRY(launch_residual(r, d_w, 0, d_result, nullptr, d, N));
     // evaluations on <omega> -> coefficients of L0, R0, O0
     ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr));
     const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
-    if (zk) HIP_TRY(hipMemcpyAsync(keep, d, 2 * N * 32, hipMemcpyDeviceToDevice, c->stream));
+    if (zk) HIP_TRY(hipMemcpyAsync(keep, d, 2 * N * 32, hipMemcpyDeviceToDevice, cur_stream(c)));
     // coset evaluations, shift = multiplicative generator g (g^N != 1)
     const H256 g = hf.generator();
     ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, &g));
     const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, c->stream, (const uint4*)d,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d,
                                          (const uint4*)(d + 2 * N), (const uint4*)(d + 4 * N), d_h, N, dev_arg(hf, zinv)));
     ACX_TRY(ntt_dev_locked(c, d_h, r->log_n, 1, 1, &g));
     if (zk) {
@@ -1419,12 +1532,12 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
         const uint4* R0 = L0 + 2 * N;
         const H256 d12 = hf.mul(dl[0], dl[1]);
         DISPATCH_FIELD(c, {
-            hipLaunchKernelGGL((k_axpy2<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, c->stream, d_h, R0, L0, N,
+            hipLaunchKernelGGL((k_axpy2<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, R0, L0, N,
                                dev_arg(hf, dl[0]), dev_arg(hf, dl[1]));
-            hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, c->stream, d_h, N, dev_arg(hf, hf.add(d12, dl[2])), dev_arg(hf, d12));
+            hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, cur_stream(c), d_h, N, dev_arg(hf, hf.add(d12, dl[2])), dev_arg(hf, d12));
         });
     } else {
-        HIP_TRY(hipMemsetAsync(d_h + 2 * N, 0, 32, c->stream));
+        HIP_TRY(hipMemsetAsync(d_h + 2 * N, 0, 32, cur_stream(c)));
     }
     HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -1435,9 +1548,11 @@ int acx_qap_h_dev(acx_r1cs* r, const void* d_witness, const acx_fr* delta, void*
     acx_ctx* c = r->ctx;
     H256 dl[3];
     if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], c->hf, dl[k]));
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    return qap_h_dev_locked(r, (const uint4*)d_witness, delta ? dl : nullptr, (uint4*)d_h, (unsigned long long*)d_result);
+    const uint64_t N = 1ull << r->log_n;
+    if (!r->qh) HIP_TRY(hipMalloc((void**)&r->qh, 5 * N * 32));      // scratch of the device-pointer path: lives with the system
+    return qap_h_dev_locked(r, (const uint4*)d_witness, delta ? dl : nullptr, (uint4*)d_h, (unsigned long long*)d_result, r->qh);
 }
 
 int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok) {
@@ -1447,18 +1562,20 @@ int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* o
     if ((int)r->log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
     H256 dl[3];
     if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], hf, dl[k]));
-    std::lock_guard<std::mutex> lock(c->mu);
+    LaneGuard lane(c);
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t N = 1ull << r->log_n;
-    DevBuf hbuf;
-    ACX_TRY(hbuf.alloc(2 * (N + 1) * 32));                 // h (N+1) + conversion scratch
-    uint4* d_h = hbuf.as<uint4>();
-    ACX_TRY(upload_elements(c, witness, r->m, r->d_w));
+    uint8_t* base = nullptr;
+    const size_t wb = align256(r->m * 32), hb = align256(2 * (N + 1) * 32);      // witness | h (N+1) + conversion scratch | 5N pipeline scratch
+    ACX_TRY(lane_reserve(c, wb + hb + 5 * N * 32, &base));
+    uint4* d_wit = (uint4*)base;
+    uint4* d_h = (uint4*)(base + wb);
+    ACX_TRY(upload_elements(c, witness, r->m, d_wit));
     const unsigned long long init[2] = {0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(c->d_result, init, 16, hipMemcpyHostToDevice, c->stream));
-    ACX_TRY(qap_h_dev_locked(r, r->d_w, delta ? dl : nullptr, d_h, c->d_result));
+    HIP_TRY(hipMemcpyAsync(cur_result(c), init, 16, hipMemcpyHostToDevice, cur_stream(c)));
+    ACX_TRY(qap_h_dev_locked(r, d_wit, delta ? dl : nullptr, d_h, cur_result(c), (uint4*)(base + wb + hb)));
     unsigned long long res[2];
-    HIP_TRY(hipMemcpyAsync(res, c->d_result, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(res, cur_result(c), 16, hipMemcpyDeviceToHost, cur_stream(c)));
     ACX_TRY(download_elements(c, d_h, N + 1, out_h, d_h + 2 * (N + 1)));
     *ok = res[0] == 0;
     uint64_t len = N + 1;
@@ -1468,43 +1585,55 @@ int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* o
     return ACX_OK;
 }
 
+int acx_qap_columns_dev(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, void* d_out, uint64_t* d_len) {
+    if (!r || matrix < 0 || matrix > 2 || !d_out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
+    acx_ctx* c = r->ctx;
+    CtxLock lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    ACX_TRY(ensure_csc(r));
+    return qap_columns_core(r, matrix, wire_begin, wire_count, (uint4*)d_out, (unsigned long long*)d_len);
+}
+
 int acx_qap_columns(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out,
                     uint64_t* out_len) {
     if (!r || matrix < 0 || matrix > 2 || !out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
     if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
+    if (wire_count == 0) return ACX_OK;
     acx_ctx* c = r->ctx;
-    std::lock_guard<std::mutex> lock(c->mu);
+    LaneGuard lane(c);
     HIP_TRY(hipSetDevice(c->device));
     ACX_TRY(ensure_csc(r));
     const uint64_t N = 1ull << r->log_n;
-    // stream wire batches: bounded device scratch (<= ~2 GiB per batch)
-    const uint64_t max_batch = std::max<uint64_t>(1, (1ull << 31) / (N * 32));
-    DevBuf buf, tmp;
-    const uint64_t chunk = std::min(max_batch, std::max<uint64_t>(wire_count, 1));
-    ACX_TRY(buf.alloc(chunk * N * 32));
-    ACX_TRY(tmp.alloc(chunk * N * 32));
-    const DevMatrix& T = r->T[matrix];
-    static const uint8_t zero32[32] = {0};
-    for (uint64_t w0 = 0; w0 < wire_count; w0 += chunk) {
-        const uint64_t cnt = std::min(chunk, wire_count - w0);
-        HIP_TRY(hipMemsetAsync(buf.p, 0, cnt * N * 32, c->stream));
-        if (T.nnz) {
-            hipLaunchKernelGGL(k_scatter_columns, dim3(grid_for(c, T.nnz)), dim3(kBlock), 0, c->stream,
-                               (const u32*)T.ptr, (const u32*)T.idx, (const uint4*)T.val, wire_begin + w0, cnt,
-                               r->log_n, buf.as<uint4>());
-        }
-        ACX_TRY(ntt_dev_locked(c, buf.as<uint4>(), r->log_n, cnt, 1, nullptr));
-        ACX_TRY(download_elements(c, buf.as<uint4>(), cnt * N, out + w0 * N, tmp.as<uint4>()));
-        if (out_len) {
-            for (uint64_t w = 0; w < cnt; ++w) {
-                uint64_t len = N;
-                const acx_fr* col = out + (w0 + w) * N;
-                while (len > 0 && std::memcmp(col[len - 1].b, zero32, 32) == 0) --len;
-                out_len[w0 + w] = len;
-            }
-        }
+    // Wire batches of bounded size (<= 1 GiB of coefficients each), double buffered: while the host thread sits in
+    // the blocking device-to-host copy of batch k (on the lane's copy stream), batch k+1 is already scattered and
+    // transformed on the lane's compute stream.
+    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(1, (1ull << 30) / (N * 32)), wire_count);
+    const size_t cb = align256(chunk * N * 32), lb = align256(chunk * 8);
+    uint8_t* base = nullptr;
+    ACX_TRY(lane_reserve(c, 2 * (cb + lb), &base));
+    acx_ctx::Lane* ln = t_lane;
+    if (!ln->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ln->copy_stream, hipStreamNonBlocking));
+    if (!ln->ev[0]) for (auto& e : ln->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    auto buf = [&](uint64_t k) { return (uint4*)(base + (k & 1) * (cb + lb)); };
+    auto lens = [&](uint64_t k) { return (unsigned long long*)(base + (k & 1) * (cb + lb) + cb); };
+    auto fetch = [&](uint64_t k) -> int {          // batch k: wait for its kernels, copy coefficients (+ lengths) out
+        const uint64_t w0 = k * chunk, cnt = std::min(chunk, wire_count - w0);
+        HIP_TRY(hipStreamWaitEvent(ln->copy_stream, ln->ev[k & 1], 0));
+        HIP_TRY(hipMemcpyAsync(out + w0 * N, buf(k), cnt * N * 32, hipMemcpyDeviceToHost, ln->copy_stream));
+        if (out_len) HIP_TRY(hipMemcpyAsync(out_len + w0, lens(k), cnt * 8, hipMemcpyDeviceToHost, ln->copy_stream));
+        HIP_TRY(hipStreamSynchronize(ln->copy_stream));
+        return ACX_OK;
+    };
+    const uint64_t n_chunks = (wire_count + chunk - 1) / chunk;
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+        const uint64_t w0 = k * chunk, cnt = std::min(chunk, wire_count - w0);
+        ACX_TRY(qap_columns_core(r, matrix, wire_begin + w0, cnt, buf(k), lens(k)));
+        ACX_TRY(launch_convert(c, false, buf(k), buf(k), cnt * N, nullptr));     // dev -> canonical in place
+        HIP_TRY(hipEventRecord(ln->ev[k & 1], cur_stream(c)));
+        if (k > 0) ACX_TRY(fetch(k - 1));          // blocks the host; the GPU works on batch k meanwhile
     }
-    return ACX_OK;
+    return fetch(n_chunks - 1);
 }
 
 // ---------------------------------------------------------------------------------- NTT
@@ -1512,7 +1641,7 @@ int acx_ntt(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_f
             acx_fr* out) {
     if (!c || !in || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
-    std::lock_guard<std::mutex> lock(c->mu);
+    LaneGuard lane(c);
     HIP_TRY(hipSetDevice(c->device));
     H256 sh;
     if (shift) {
@@ -1521,25 +1650,25 @@ int acx_ntt(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_f
     }
     const uint64_t total = batch << log_n;
     if (total == 0) return ACX_OK;
-    DevBuf buf, tmp;
-    ACX_TRY(buf.alloc(total * 32));
-    ACX_TRY(tmp.alloc(total * 32));
-    ACX_TRY(upload_elements(c, in, total, buf.as<uint4>()));
-    ACX_TRY(ntt_dev_locked(c, buf.as<uint4>(), log_n, batch, inverse, shift ? &sh : nullptr));
-    return download_elements(c, buf.as<uint4>(), total, out, tmp.as<uint4>());
+    uint8_t* base = nullptr;
+    ACX_TRY(lane_reserve(c, 2 * total * 32, &base));
+    uint4* buf = (uint4*)base;
+    ACX_TRY(upload_elements(c, in, total, buf));
+    ACX_TRY(ntt_dev_locked(c, buf, log_n, batch, inverse, shift ? &sh : nullptr));
+    return download_elements(c, buf, total, out, buf + 2 * total);
 }
 
 // ---------------------------------------------------------------------------------- device API
 int acx_dev_from_canonical(acx_ctx* c, uint64_t count, const void* d_in, void* d_out, uint32_t* d_err) {
     if (!c || !d_in || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     return launch_convert(c, true, d_in, d_out, count, d_err);
 }
 
 int acx_dev_to_canonical(acx_ctx* c, uint64_t count, const void* d_in, void* d_out) {
     if (!c || !d_in || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     return launch_convert(c, false, d_in, d_out, count, nullptr);
 }
@@ -1547,7 +1676,7 @@ int acx_dev_to_canonical(acx_ctx* c, uint64_t count, const void* d_in, void* d_o
 int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset, uint64_t* d_result,
                         void* d_residuals, void* d_dots) {
     if (!r || !d_witness || !d_result) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lock(r->ctx->mu);
+    CtxLock lock(r->ctx->mu);
     HIP_TRY(hipSetDevice(r->ctx->device));
     return launch_residual(r, (const uint4*)d_witness, row_offset, (unsigned long long*)d_result,
                            (uint4*)d_residuals, (uint4*)d_dots, 1ull << r->log_n);
@@ -1562,9 +1691,9 @@ int acx_qap_pointwise_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_
     ACX_TRY(read_h256(shift, hf, g));
     const H256 z = hf.sub(hf.pow_u64(g, 1ull << log_n), hf.one());
     if (z.is_zero()) return fail(ACX_ERR_INVALID_ARG, "shift^N = 1: the coset meets the evaluation domain");
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, (const uint4*)d_a,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d_a,
                                          (const uint4*)d_b, (const uint4*)d_c, (uint4*)d_out, count, dev_arg(hf, hf.inv(z))));
     HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -1573,7 +1702,7 @@ int acx_qap_pointwise_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_
 int acx_ntt_dist_step_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
                           const acx_fr* shift, const void* d_in, void* d_out) {
     if (!c || !d_in || !d_out || (step != 0 && step != 1)) return fail(ACX_ERR_INVALID_ARG, "bad argument");
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     H256 sh;
     if (shift) {
@@ -1588,9 +1717,9 @@ int acx_ntt_dist_step_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t w
 void acx_naive_destroy(acx_naive* nv) {
     if (!nv) return;
     {
-        std::lock_guard<std::mutex> lock(nv->r->ctx->mu);
+        CtxLock lock(nv->r->ctx->mu);
         (void)hipSetDevice(nv->r->ctx->device);
-        (void)hipStreamSynchronize(nv->r->ctx->stream);
+        (void)hipDeviceSynchronize();        // every lane: nothing may still be using this object
         if (nv->roots) (void)hipFree(nv->roots);
         if (nv->tcoef) (void)hipFree(nv->tcoef);
         if (nv->winv) (void)hipFree(nv->winv);
@@ -1614,7 +1743,7 @@ int acx_naive_create(acx_r1cs* r, const acx_fr* roots, uint64_t n_roots, acx_nai
             if (h256_cmp(b, a) >= 0) return fail(ACX_ERR_DUPLICATE_ROOT, "roots must be distinct and ascending (row order)");
         }
     }
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     acx_naive* nv = new (std::nothrow) acx_naive();
     if (!nv) return fail(ACX_ERR_OOM, "host allocation failed");
@@ -1638,12 +1767,12 @@ int acx_naive_create(acx_r1cs* r, const acx_fr* roots, uint64_t n_roots, acx_nai
         for (int i = 0; i < 8; ++i) pm2.w[i] = (u32)(e.l[i / 2] >> (32 * (i % 2)));
     }
     DISPATCH_FIELD(c, {
-        hipLaunchKernelGGL((k_poly_from_roots<F>), dim3(1), dim3(1024), 0, c->stream, (const uint4*)nv->roots, n, nv->tcoef, tmp.as<uint4>());
-        hipLaunchKernelGGL((k_bary_inv<F>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const uint4*)nv->roots, n, nv->winv, pm2);
-        hipLaunchKernelGGL((k_build_q<F>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const uint4*)nv->roots,
+        hipLaunchKernelGGL((k_poly_from_roots<F>), dim3(1), dim3(1024), 0, cur_stream(c), (const uint4*)nv->roots, n, nv->tcoef, tmp.as<uint4>());
+        hipLaunchKernelGGL((k_bary_inv<F>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, cur_stream(c), (const uint4*)nv->roots, n, nv->winv, pm2);
+        hipLaunchKernelGGL((k_build_q<F>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, cur_stream(c), (const uint4*)nv->roots,
                            (const uint4*)nv->tcoef, (const uint4*)nv->winv, n, nv->Q);
     });
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(ACX_ERR_HIP, "naive setup kernels failed"));
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(cur_stream(c)) != hipSuccess) return bail(fail(ACX_ERR_HIP, "naive setup kernels failed"));
     *out = nv;
     return ACX_OK;
 }
@@ -1651,7 +1780,7 @@ int acx_naive_create(acx_r1cs* r, const acx_fr* roots, uint64_t n_roots, acx_nai
 int acx_naive_target(acx_naive* nv, acx_fr* out) {
     if (!nv || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = nv->r->ctx;
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     DevBuf tmp;
     ACX_TRY(tmp.alloc((size_t)(nv->n + 1) * 32));
@@ -1665,7 +1794,7 @@ int acx_naive_columns(acx_naive* nv, int matrix, uint64_t wire_begin, uint64_t w
     if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
     if (wire_count == 0) return ACX_OK;
     acx_ctx* c = r->ctx;
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     ACX_TRY(ensure_csc(r));
     const uint64_t N = 1ull << r->log_n, n = nv->n;
@@ -1673,12 +1802,12 @@ int acx_naive_columns(acx_naive* nv, int matrix, uint64_t wire_begin, uint64_t w
     ACX_TRY(dense.alloc(wire_count * N * 32));
     ACX_TRY(res.alloc(wire_count * n * 32));
     ACX_TRY(tmp.alloc(wire_count * n * 32));
-    HIP_TRY(hipMemsetAsync(dense.p, 0, wire_count * N * 32, c->stream));
+    HIP_TRY(hipMemsetAsync(dense.p, 0, wire_count * N * 32, cur_stream(c)));
     const DevMatrix& T = r->T[matrix];
     if (T.nnz)
-        hipLaunchKernelGGL(k_scatter_columns, dim3(grid_for(c, T.nnz)), dim3(kBlock), 0, c->stream, (const u32*)T.ptr,
-                           (const u32*)T.idx, (const uint4*)T.val, wire_begin, wire_count, r->log_n, dense.as<uint4>());
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_matvec_q<F>), dim3(grid_for(c, wire_count * n)), dim3(kBlock), 0, c->stream,
+        hipLaunchKernelGGL(k_scatter_columns, dim3(grid_for(c, T.nnz)), dim3(kBlock), 0, cur_stream(c), (const u32*)T.ptr,
+                           (const u32*)T.idx, (const u32*)T.colid, (const uint4*)T.val, wire_begin, wire_count, r->log_n, dense.as<uint4>());
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_matvec_q<F>), dim3(grid_for(c, wire_count * n)), dim3(kBlock), 0, cur_stream(c),
                                          (const uint4*)dense.as<uint4>(), N, (const uint4*)nv->Q, (u32)n, wire_count,
                                          res.as<uint4>(), n));
     HIP_TRY(hipGetLastError());
@@ -1699,7 +1828,7 @@ int acx_naive_h(acx_naive* nv, const acx_fr* witness, const acx_fr* delta, acx_f
     acx_r1cs* r = nv->r;
     acx_ctx* c = r->ctx;
     const HostField& hf = c->hf;
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t N = 1ull << r->log_n;
     const uint32_t n = nv->n, np1 = n + 1;
@@ -1708,39 +1837,39 @@ int acx_naive_h(acx_naive* nv, const acx_fr* witness, const acx_fr* delta, acx_f
     ACX_TRY(lro.alloc((size_t)3 * np1 * 32));
     ACX_TRY(prod.alloc((size_t)(2 * np1) * 32));
     ACX_TRY(quot.alloc((size_t)(np1 + 1) * 32));
-    HIP_TRY(hipMemsetAsync(dots.p, 0, 3 * N * 32, c->stream));
-    HIP_TRY(hipMemsetAsync(lro.p, 0, (size_t)3 * np1 * 32, c->stream));
-    HIP_TRY(hipMemsetAsync(quot.p, 0, (size_t)(np1 + 1) * 32, c->stream));
+    HIP_TRY(hipMemsetAsync(dots.p, 0, 3 * N * 32, cur_stream(c)));
+    HIP_TRY(hipMemsetAsync(lro.p, 0, (size_t)3 * np1 * 32, cur_stream(c)));
+    HIP_TRY(hipMemsetAsync(quot.p, 0, (size_t)(np1 + 1) * 32, cur_stream(c)));
     uint64_t bad = 0;
-    ACX_TRY(verify_common(r, witness, &bad, nullptr, nullptr, dots.as<uint4>(), N));
+    ACX_TRY(verify_common(r, witness, r->d_w, &bad, nullptr, nullptr, dots.as<uint4>(), N));
     H256 dl[3] = {hf.zero(), hf.zero(), hf.zero()};
     if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], hf, dl[k]));
     uint4* L = lro.as<uint4>();
     uint4* R = L + 2 * (u64)np1;
     uint4* O = R + 2 * (u64)np1;
     // L0, R0, O0 = interpolants of the dot products on the roots (n coefficients each, stride n+1)
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_matvec_q<F>), dim3(grid_for(c, 3ull * n)), dim3(kBlock), 0, c->stream,
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_matvec_q<F>), dim3(grid_for(c, 3ull * n)), dim3(kBlock), 0, cur_stream(c),
                                          (const uint4*)dots.as<uint4>(), N, (const uint4*)nv->Q, n, (u64)3, L, (u64)np1));
     // + delta_k * T   (src/QAP.hs:315-323)
     const FeArg one = dev_arg(hf, hf.one());
     for (int k = 0; k < 3; ++k)
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_poly_axpby<F>), dim3(grid_for(c, np1)), dim3(kBlock), 0, c->stream,
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_poly_axpby<F>), dim3(grid_for(c, np1)), dim3(kBlock), 0, cur_stream(c),
                                              L + 2 * (u64)k * np1, (const uint4*)nv->tcoef, np1, one, dev_arg(hf, dl[k])));
     // P = L*R - O  (2n+1 coefficients), then quotRem by T
     DISPATCH_FIELD(c, {
-        hipLaunchKernelGGL((k_poly_mul<F>), dim3((2 * np1 - 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+        hipLaunchKernelGGL((k_poly_mul<F>), dim3((2 * np1 - 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, cur_stream(c),
                            (const uint4*)L, np1, (const uint4*)R, np1, prod.as<uint4>());
-        hipLaunchKernelGGL((k_poly_axpby<F>), dim3(grid_for(c, np1)), dim3(kBlock), 0, c->stream, prod.as<uint4>(),
+        hipLaunchKernelGGL((k_poly_axpby<F>), dim3(grid_for(c, np1)), dim3(kBlock), 0, cur_stream(c), prod.as<uint4>(),
                            (const uint4*)O, np1, one, dev_arg(hf, hf.neg(hf.one())));
-        hipLaunchKernelGGL((k_poly_divrem_monic<F>), dim3(1), dim3(1024), 0, c->stream, prod.as<uint4>(), 2 * np1 - 1,
+        hipLaunchKernelGGL((k_poly_divrem_monic<F>), dim3(1), dim3(1024), 0, cur_stream(c), prod.as<uint4>(), 2 * np1 - 1,
                            (const uint4*)nv->tcoef, n, quot.as<uint4>());
     });
-    HIP_TRY(hipMemsetAsync(c->d_err, 0, 4, c->stream));
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_any_nonzero<F>), dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream,
-                                         (const uint4*)prod.as<uint4>(), n, c->d_err));
+    HIP_TRY(hipMemsetAsync(cur_err(c), 0, 4, cur_stream(c)));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_any_nonzero<F>), dim3(grid_for(c, n)), dim3(kBlock), 0, cur_stream(c),
+                                         (const uint4*)prod.as<uint4>(), n, cur_err(c)));
     HIP_TRY(hipGetLastError());
     uint32_t rem_nonzero = 0;
-    HIP_TRY(hipMemcpyAsync(&rem_nonzero, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&rem_nonzero, cur_err(c), 4, hipMemcpyDeviceToHost, cur_stream(c)));
     ACX_TRY(download_elements(c, quot.as<uint4>(), np1, out_h, lro.as<uint4>()));
     *ok = rem_nonzero == 0;
     if ((bad == 0) != (*ok != 0)) return fail(ACX_ERR_HIP, "internal: division remainder disagrees with the residual check");
@@ -1755,7 +1884,7 @@ int acx_batch_create(acx_ctx* ctx, uint64_t count, acx_r1cs* const* systems, con
                      uint64_t* d_results, uint64_t result_stride, acx_batch** out) {
     if (!ctx || !systems || !d_witnesses || !d_results || !out || count == 0 || count > 65535)
         return fail(ACX_ERR_INVALID_ARG, "bad batch arguments");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    CtxLock lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     acx_batch* b = new (std::nothrow) acx_batch();
     if (!b) return fail(ACX_ERR_OOM, "host allocation failed");
@@ -1785,9 +1914,9 @@ int acx_batch_create(acx_ctx* ctx, uint64_t count, acx_r1cs* const* systems, con
 void acx_batch_destroy(acx_batch* b) {
     if (!b) return;
     {
-        std::lock_guard<std::mutex> lock(b->ctx->mu);
+        CtxLock lock(b->ctx->mu);
         (void)hipSetDevice(b->ctx->device);
-        (void)hipStreamSynchronize(b->ctx->stream);
+        (void)hipDeviceSynchronize();        // every lane: nothing may still be using this object
         if (b->d_systems) (void)hipFree(b->d_systems);
     }
     delete b;
@@ -1796,11 +1925,11 @@ void acx_batch_destroy(acx_batch* b) {
 int acx_batch_verify_dev(acx_batch* b) {
     if (!b) return fail(ACX_ERR_INVALID_ARG, "null batch");
     acx_ctx* c = b->ctx;
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     if (b->max_slices) {
         const dim3 grid(sell_grid_x(b->max_slices), (unsigned)b->systems.size(), 1);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, c->stream,
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, cur_stream(c),
                                              (const SellSystem*)b->d_systems, SellSystem{}));
         HIP_TRY(hipGetLastError());
     }
@@ -1811,7 +1940,7 @@ int acx_batch_verify_dev(acx_batch* b) {
 
 int acx_ntt_dev(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift, void* d_data) {
     if (!c || !d_data) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lock(c->mu);
+    CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     H256 sh;
     if (shift) {

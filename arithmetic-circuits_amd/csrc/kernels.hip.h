@@ -688,25 +688,90 @@ __global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, Cs
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6: densify columns [wire_begin, wire_begin+wire_count) of one matrix from its CSC form into
-// out[w][0..N) (zero filled beforehand) -- the per-wire `Map root value` of the GenQAP
-// (src/QAP.hs:94-99) after `addMissingZeroes` (src/QAP.hs:566-576), only for a batch of wires.
-__global__ __launch_bounds__(kBlock) void k_scatter_columns(const u32* __restrict__ colptr,
-                                                           const u32* __restrict__ rowidx,
-                                                           const uint4* __restrict__ val, u64 wire_begin,
-                                                           u64 wire_count, u32 log_n, uint4* __restrict__ out) {
+// K6: `createPolynomialsFFT` (src/QAP.hs:512-525) for a batch of wires: the column view (CSC) of a matrix is built
+// on the device once, a batch of columns is densified into zeroed length-N buffers -- the per-wire `Map root value`
+// of the GenQAP (src/QAP.hs:94-99) after `addMissingZeroes` (src/QAP.hs:566-576), for these wires only -- and the
+// batched inverse NTT interpolates them.
+
+// count[c] += 1 for every stored entry of column c
+__global__ __launch_bounds__(kBlock) void k_col_histogram(const u32* __restrict__ col, u64 nnz, u32* __restrict__ count) {
+    for (u64 e = (u64)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (u64)gridDim.x * kBlock) atomicAdd(&count[col[e]], 1u);
+}
+
+// out[i] = in[0] + ... + in[i-1] for i <= n (one workgroup: a one-off pass over m counters)
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const u32* __restrict__ in, u32* __restrict__ out, u64 n) {
+    __shared__ u32 buf[1024];
+    __shared__ u32 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < n; base += 1024) {
+        const u64 i = base + threadIdx.x;
+        const u32 v = i < n ? in[i] : 0u;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (u32 off = 1; off < 1024; off <<= 1) {             // Hillis-Steele inclusive scan
+            const u32 t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0u;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) out[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+// CSR -> CSC: entry e of row i goes to slot colptr[c] + (a ticket of column c).  The order inside a column is
+// whatever the atomics give; nothing downstream depends on it (rows of a column are distinct after normalisation).
+__global__ __launch_bounds__(kBlock) void k_csc_fill(CsrDev M, u64 n_rows, const u32* __restrict__ colptr, u32* __restrict__ cursor,
+                                                    u32* __restrict__ rowidx, u32* __restrict__ colid, uint4* __restrict__ tval) {
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n_rows; i += (u64)gridDim.x * kBlock) {
+        for (u32 e = M.rowptr[i]; e < M.rowptr[i + 1]; ++e) {
+            const u32 c = M.col[e];
+            const u32 dst = colptr[c] + atomicAdd(&cursor[c], 1u);
+            rowidx[dst] = (u32)i;
+            colid[dst] = c;
+            tval[2 * (u64)dst] = M.val[2 * (u64)e];
+            tval[2 * (u64)dst + 1] = M.val[2 * (u64)e + 1];
+        }
+    }
+}
+
+// densify columns [wire_begin, wire_begin + wire_count) into out[w][0..N) (zero filled beforehand); every entry
+// carries its column id, so there is no search
+__global__ __launch_bounds__(kBlock) void k_scatter_columns(const u32* __restrict__ colptr, const u32* __restrict__ rowidx,
+                                                           const u32* __restrict__ colid, const uint4* __restrict__ val,
+                                                           u64 wire_begin, u64 wire_count, u32 log_n, uint4* __restrict__ out) {
     const u64 e_begin = colptr[wire_begin], e_end = colptr[wire_begin + wire_count];
     for (u64 e = e_begin + (u64)blockIdx.x * kBlock + threadIdx.x; e < e_end; e += (u64)gridDim.x * kBlock) {
-        // locate the column of entry e by binary search in colptr[wire_begin .. wire_begin+wire_count]
-        u64 lo = wire_begin, hi = wire_begin + wire_count;
-        while (hi - lo > 1) {
-            const u64 mid = (lo + hi) >> 1;
-            if (colptr[mid] <= e) lo = mid; else hi = mid;
-        }
-        uint4* dst = out + 2 * (((lo - wire_begin) << log_n) + rowidx[e]);
+        uint4* dst = out + 2 * (((u64)(colid[e] - wire_begin) << log_n) + rowidx[e]);
         dst[0] = val[2 * e];
         dst[1] = val[2 * e + 1];
     }
+}
+
+// len[w] = 1 + index of the last nonzero coefficient of polynomial w (0 for the zero polynomial): poly's `toPoly`
+// stripping, computed where the data is.  One workgroup per polynomial, scanning down from the top.
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_poly_len(const uint4* __restrict__ data, u32 log_n, unsigned long long* __restrict__ len) {
+    const u64 N = 1ull << log_n;
+    const uint4* p = data + 2 * ((u64)blockIdx.x << log_n);
+    __shared__ u32 best;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    for (u64 top = N; top > 0;) {
+        const u64 base = top > kBlock ? top - kBlock : 0;
+        const u64 i = base + threadIdx.x;
+        if (i < top && !fe_is_zero<F>(fe_load(p + 2 * i))) atomicMax(&best, (u32)(i + 1));
+        __syncthreads();
+        const u32 found = best;
+        __syncthreads();                                        // nobody updates `best` again before everyone has read it
+        if (found != 0) break;                                  // uniform
+        top = base;
+    }
+    if (threadIdx.x == 0) len[blockIdx.x] = best;
 }
 
 }  // namespace acx

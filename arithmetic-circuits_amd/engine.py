@@ -206,6 +206,9 @@ class R1CS:
         check(self.ctx.lib.acx_qap_columns(self._h, matrix, wire_begin, wire_count, _ptr(out), _ptr(lens)))
         return out, lens
 
+    def qap_columns_dev(self, matrix: int, wire_begin: int, wire_count: int, d_out: int, d_len: int = 0) -> None:
+        check(self.ctx.lib.acx_qap_columns_dev(self._h, matrix, wire_begin, wire_count, d_out, d_len or None))
+
     def verify_dev(self, d_witness: int, d_result: int, row_offset: int = 0, d_residuals: int = 0, d_dots: int = 0) -> None:
         check(self.ctx.lib.acx_r1cs_verify_dev(self._h, d_witness, row_offset, d_result, d_residuals or None, d_dots or None))
 

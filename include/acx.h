@@ -15,7 +15,11 @@
  *   - Caller owns every host buffer; the library owns device memory behind opaque handles.
  *   - Every function returns 0 (ACX_OK) or a negative acx_status; nothing aborts or throws
  *     across the ABI (the reference's `panic` sites become error codes).
- *   - Entry points are thread-safe; each sets its device and uses its context's streams.
+ *   - Entry points are thread-safe; each sets its device and uses its context's streams.  The host-buffer entry
+ *     points that block on the GPU (acx_r1cs_verify, acx_r1cs_residuals, acx_qap_h, acx_qap_columns, acx_ntt) run
+ *     concurrently for up to four callers per context (one HIP stream + scratch arena each): `safe` foreign
+ *     calls from several Haskell capabilities overlap (test/Test/Circuit/Arithmetic.hs:209 maps verifyAssignment
+ *     over many inputs).  The device-pointer entry points share the single stream acx_ctx_stream() returns.
  *   - There is NO CPU fallback: without a usable gfx950 device acx_ctx_create fails with
  *     ACX_ERR_NO_DEVICE and nothing else can be called.
  */
@@ -184,7 +188,7 @@ int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad
  * resident on the device for acx_r1cs_verify_resident. */
 int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs,
                   acx_fr* witness, uint8_t* assigned);
-/* verifyAssignment of the witness left on the device by acx_r1cs_eval / acx_r1cs_verify. */
+/* verifyAssignment of the witness left on the device by acx_r1cs_eval. */
 int acx_r1cs_verify_resident(acx_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* first_bad);
 /* Residual vector r_i (canonical), out[n]. */
 int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out);
@@ -248,6 +252,11 @@ int acx_ntt_dev(acx_ctx* ctx, uint32_t log_n, uint64_t batch, int inverse, const
  * N+1 dev elements = the quotient's coefficients low to high, zero beyond its degree (not stripped);
  * d_result {n_bad, first_bad} accumulates like acx_r1cs_verify_dev (n_bad != 0 <=> `Nothing`).  delta may be NULL. */
 int acx_qap_h_dev(acx_r1cs* r, const void* d_witness, const acx_fr* delta, void* d_h, uint64_t* d_result);
+/* `createPolynomialsFFT` (src/QAP.hs:512-525) with the results left on the device: d_out receives wire_count * N
+ * dev elements (column w at d_out + w*N), d_len (may be NULL) the stripped lengths (`toPoly`), computed by a
+ * reduction on the device.  The column view of the matrix is built on the device on first use. */
+int acx_qap_columns_dev(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, void* d_out,
+                        uint64_t* d_len);
 
 /* Local step of the DISTRIBUTED four-step NTT (replaces galois-fft at src/QAP.hs:521-524 when one
  * transform spans several GPUs, BASELINE.json configs[3]).  N = 2^log_n = R*C with R = 2^log_r; index split

@@ -236,3 +236,28 @@ def test_root_count_validation_through_the_abi(acx):
         with pytest.raises(acx.AcxError) as e:
             prog.check_root_counts(bad)
         assert e.value.status == acx._lib.STATUS["ROOT_COUNT"]
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = str(tmp_path / "example_hs")
+    libdir = os.path.abspath(os.path.join(root, "arithmetic-circuits_amd"))
+    cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "example_hs.c"),
+           "-L", libdir, "-lacx", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_c_host_links_against_the_abi_and_fails_loudly_without_a_gpu(acx, tmp_path):
+    """tests/c/example_hs.c (Example.hs driven through include/acx.h from plain C, no Python in between)
+    compiles with gcc against libacx.so; on a box without a GPU its host half runs (marshalling, dims,
+    generateAssignment) and the first device call fails with ACX_ERR_NO_DEVICE (exit 77) -- no fallback."""
+    import subprocess, torch
+    acx._lib.load()
+    exe = _build_c_example(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert out.returncode == 0 and "Valid assignment" in out.stdout, out.stderr
+    else:
+        assert out.returncode == 77 and "no usable HIP device" in out.stderr, (out.returncode, out.stderr)
