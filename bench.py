@@ -454,7 +454,7 @@ def main():
                                 "frac_median": bytes_per_launch / bs[len(bs) // 2] * 1e-3 / HBM_PEAK_GBS,
                                 "note": "kernel times at the sustained clock (0.25 s untimed pre-run before the timed region)"}
         try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["acx::k_r1cs_sell"]
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["acx::k_r1cs_sell"]
             if tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr["source"]

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Per-rank time budget of the distributed configs[3] job, measured on ONE GPU: the local work of rank 0 of a
+W-rank job (W = 8 by default) is exactly reproducible without the other ranks -- the local steps of the
+four-step transform take (world, rank) as plain arguments, the rank's block-cyclic rows are marshalled from the
+row source, and the all-to-all moves a known number of bytes.  Prints microseconds per local step (HIP events on
+libacx's stream) and the exchange volume, from which the 8-GPU time of one distributed h(x) follows:
+
+    t = residual_dots + 3 * (inv0 + inv1) + 3 * (fwd0c + fwd1) + pointwise + (inv0 + inv1c) + 7 * exchange + all-reduce
+
+python tools/dist_budget.py [--world 8] [--logn 24]   (run under rocprofv3 --kernel-trace for the kernel view)"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+acx = importlib.import_module("arithmetic-circuits_amd")
+synth = importlib.import_module("arithmetic-circuits_amd.synth")
+par = importlib.import_module("arithmetic-circuits_amd.parallel")
+
+
+def timed(stream, fn, reps=10):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--logn", type=int, default=24)
+    ap.add_argument("--field", default="bn254")
+    a = ap.parse_args()
+    W, ln, lr = a.world, a.logn, a.logn // 2
+    ctx = acx.Context(a.field, 0)
+    stream = torch.cuda.ExternalStream(ctx.stream)
+    g = 5 if a.field == "bn254" else 7
+    L = (1 << ln) // W
+    x = torch.from_numpy(synth.random_fr(L, 1, 1, a.field).view(np.int64).copy()).cuda()
+    torch.cuda.synchronize()
+    ctx.dev_from_canonical(L, x.data_ptr(), x.data_ptr())
+    y = torch.empty_like(x)
+    t = {}
+    for name, inv, step, shift in (("fwd0", False, 0, None), ("fwd0c", False, 0, g), ("fwd1", False, 1, None),
+                                   ("inv0", True, 0, None), ("inv1", True, 1, None), ("inv1c", True, 1, g)):
+        t[name] = timed(stream, lambda: ctx.ntt_dist_step_dev(x.data_ptr(), y.data_ptr(), ln, lr, W, 0, inv, step, shift))
+    # rank 0's rows of the 2^logn-constraint block system, block-cyclic ownership
+    bs = synth.BlockSystem(synth.mulgraph(1 << 16, seed=0xAC4, field=a.field), (1 << ln) >> 16)
+    rows = par.cyclic_rows(ln, lr, W, 0)
+    r = acx.R1CS.load(ctx, rows.shape[0], bs.m, *bs.rows_of(rows))
+    w = bs.witness()
+    dw = torch.from_numpy(w.view(np.int64).copy()).cuda()
+    torch.cuda.synchronize()
+    ctx.dev_from_canonical(w.shape[0], dw.data_ptr(), dw.data_ptr())
+    dots = torch.zeros((3 * L, 4), dtype=torch.int64, device="cuda")
+    res = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    t["residual_dots"] = timed(stream, lambda: r.verify_dev(dw.data_ptr(), res.data_ptr(), d_dots=dots.data_ptr()))
+    t["residual_only"] = timed(stream, lambda: r.verify_dev(dw.data_ptr(), res.data_ptr()))
+    assert int(res[0]) == 0
+    t["pointwise"] = timed(stream, lambda: ctx.qap_pointwise_dev(dots.data_ptr(), dots[L:].data_ptr(), dots[2 * L:].data_ptr(), y.data_ptr(), L, ln, g))
+    xbytes = L * 32 * (W - 1) // W
+    local = t["residual_dots"] + 3 * (t["inv0"] + t["inv1"]) + 3 * (t["fwd0c"] + t["fwd1"]) + t["pointwise"] + t["inv0"] + t["inv1c"]
+    print(f"rank-local budget of a {W}-rank job, N = 2^{ln} = 2^{lr} x 2^{ln - lr}, {a.field} Fr, {L} elements per rank (us):")
+    for k, v in t.items():
+        print(f"  {k:14s} {v:10.1f}")
+    print(f"  all-to-all: {xbytes / 2**20:.1f} MiB out per rank per transform ({xbytes // (W - 1) / 2**20:.2f} MiB per peer); 7 per h(x)")
+    for bw in (50e9, 100e9, 153e9):
+        ex = xbytes / (7 * bw) * 1e6 if W > 1 else 0.0
+        print(f"  h(x) per rank: local {local:9.1f} us + 7 exchanges at {bw / 1e9:.0f} GB/s/link x 7 links {7 * ex:8.1f} us = {local + 7 * ex:9.1f} us"
+              f" -> {(1 << ln) / (local + 7 * ex) * 1e6:.3e} constraints/s over {W} GPUs")
+    dnt = t["fwd0"] + t["fwd1"]
+    print(f"  one forward transform per rank: {dnt:.1f} us local (+ exchange)")
+
+
+if __name__ == "__main__":
+    main()
