@@ -207,6 +207,8 @@ class ShardedR1CS:
         return self.verify_dev(w, dots=out)
 
     def _reduce(self, verdict: torch.Tensor, first: torch.Tensor, want_first: bool) -> Tuple[bool, int, int]:
+        if self.world > 1 and verdict.is_cuda and dist.get_backend(self.group) == "gloo":
+            verdict, first = verdict.cpu(), first.cpu()          # several ranks on one GPU over gloo (tests)
         if self.world > 1:
             dist.all_reduce(verdict, op=dist.ReduceOp.SUM, group=self.group)          # THE verdict collective
             if want_first:
@@ -304,6 +306,15 @@ class DistributedNTT:
     def _all_to_all(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return send
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no CUDA all-to-all: stage through the host (test configurations with several ranks on one
+            # GPU; a real multi-GPU job uses the nccl = RCCL backend and never comes here)
+            torch.cuda.synchronize()
+            s = send.cpu()
+            r = torch.empty_like(s)
+            dist.all_to_all_single(r, s, group=self.group)
+            recv.copy_(r)
+            return recv
         dist.all_to_all_single(recv, send, group=self.group)
         return recv
 

@@ -178,7 +178,7 @@ def bench_distributed(ctx, a, world, rank, dist):
     dev = torch.device("cuda", torch.cuda.current_device())
 
     def tmax(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
@@ -423,7 +423,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     dist_extra = {}
-    if use_dist and not a.no_dist_pipeline and a.backend == "nccl":
+    if use_dist and not a.no_dist_pipeline:
         del batches, neg_batch
         systems.clear(); witnesses.clear()
         dist_extra = bench_distributed(ctx, a, world, rank, dist)

@@ -1,7 +1,7 @@
 """Worker for test_gpu_parity.py::test_sharded_layer_two_ranks_on_one_device: the multi-GPU host layer
 with the PRODUCT local kernels (libacx through HipOps / ShardedR1CS), two ranks sharing cuda:0 over gloo
 (RCCL needs one GPU per rank; the sharding logic and the stream fencing do not).  gloo has no CUDA
-all-to-all, so the exchange of the distributed NTT is staged through host memory here; everything else is
+all-to-all, so parallel.py stages the exchange through host memory under that backend; everything else is
 the code path of a multi-GPU run."""
 import importlib
 import os
@@ -19,18 +19,6 @@ from oracle.c_oracle import COracle                  # noqa: E402
 acx = importlib.import_module("arithmetic-circuits_amd")
 par = importlib.import_module("arithmetic-circuits_amd.parallel")
 synth = importlib.import_module("arithmetic-circuits_amd.synth")
-
-
-class StagedNTT(par.DistributedNTT):
-    def _all_to_all(self, send, recv):
-        if self.world == 1:
-            return send
-        torch.cuda.synchronize()
-        s = send.cpu()
-        r = torch.empty_like(s)
-        dist.all_to_all_single(r, s, group=self.group)
-        recv.copy_(r)
-        return recv
 
 
 def dev(ctx, arr):
@@ -75,7 +63,7 @@ def main():
     for log_n, log_r in ((12, 6), (15, 7), (16, 8)):
         N = 1 << log_n
         x = synth.random_fr(N, 11, log_n)
-        d = StagedNTT(log_n, ops, log_r=log_r)
+        d = par.DistributedNTT(log_n, ops, log_r=log_r)
         mine = dev(ctx, x[d.cols_indices()])
         for shift in (None, orc.generator):
             want = orc.ntt(x, log_n, shift=shift, nthreads=4)
@@ -90,7 +78,7 @@ def main():
     shc = par.ShardedR1CS.from_cyclic(source, n, m, log_n, log_r, ctx=ctx)
     assert shc.rows.shape[0] == n // world
     assert shc.verify(bad, want_first=True) == (False, want_bad, want_first)
-    dn = StagedNTT(log_n, ops, log_r=log_r)
+    dn = par.DistributedNTT(log_n, ops, log_r=log_r)
     qh = par.DistributedQapH(shc, dn, orc.generator)
     h, ok = qh.run(dev(ctx, w))
     want_h, want_ok = orc.qap_h(n, m, log_n, *mats, w, nthreads=4)

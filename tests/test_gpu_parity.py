@@ -825,7 +825,7 @@ def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, ACX_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20",
-           "--warmup", "3", "--copies", "4", "--no-cpu", "--no-ntt"]
+           "--warmup", "3", "--copies", "4", "--no-cpu", "--no-ntt", "--dist-logn", "18"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -835,6 +835,9 @@ def test_bench_two_ranks_on_one_device():
     assert d["config"]["constraints_per_step_per_gpu"] == 4 << 16
     assert abs(d["value"] - 2 * (4 << 16) * 20 / (d["ms_per_step"] * 20 * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and "roofline" in d
+    # the multi-rank line also times the distributed transform and the distributed h(x) (here 2^18, odd digits 9+9)
+    assert d["dist_ntt"]["parity_vs_oracle"] is True and d["dist_ntt"]["all_to_all_bytes_per_rank"] == (1 << 18) // 2 * 32 // 2
+    assert d["dist_qap_h"]["accepts_valid_rejects_corrupt"] is True and d["dist_qap_h"]["us"] > 0
 
 
 @pytest.mark.gpu
