@@ -102,6 +102,7 @@ struct acx_ctx {
         H256 base{{0, 0, 0, 0}};
         uint32_t log_n = 0;
         int scaled = 0;
+        int direct = 0;                                    // lo = the full table g^j, j < 2^log_n (hi unused)
         uint64_t stamp = 0;
     };
     CosetTables cosets[8];
@@ -368,10 +369,11 @@ int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, ui
 // g^j (j < 1024) and g^(1024 j) (j < N/1024) for the coset factor.  A small cache: the h(x) pipeline alternates
 // between g (forward) and 1/g with 1/N folded in (inverse) on every call.
 // scaled: the low table carries the factor 1/2^log_n (closing multiplication of an inverse coset transform).
-int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scaled, uint4** lo, uint4** hi) {
+// direct: ONE table of all 2^log_n powers (32 bytes each): the closing multiplication then needs no second product.
+int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scaled, uint4** lo, uint4** hi, int direct = 0) {
     CtxLock lock(c->mu);
     for (auto& e : c->cosets)
-        if (e.lo && e.base == base_mont && e.log_n == log_n && e.scaled == scaled) {
+        if (e.lo && e.base == base_mont && e.log_n == log_n && e.scaled == scaled && e.direct == direct) {
             e.stamp = ++c->coset_clock;
             *lo = e.lo; *hi = e.hi;
             return ACX_OK;
@@ -385,11 +387,12 @@ int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scal
         if (slot->hi) (void)hipFree(slot->hi);
         slot->lo = slot->hi = nullptr;
     }
-    const uint64_t hi_count = log_n > 10 ? (1ull << (log_n - 10)) : 0;
-    HIP_TRY(hipMalloc((void**)&slot->lo, 1024 * 32));
+    const uint64_t hi_count = (!direct && log_n > 10) ? (1ull << (log_n - 10)) : 0;
+    const uint64_t lo_count = direct ? (1ull << log_n) : 1024;
+    HIP_TRY(hipMalloc((void**)&slot->lo, lo_count * 32));
     const H256 first = scaled ? c->hf.inv(c->hf.from_u64(1ull << log_n)) : c->hf.one();
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(4), dim3(kBlock), 0, cur_stream(c), slot->lo,
-                                         (u64)1024, dev_arg(c->hf, base_mont), dev_arg(c->hf, first)));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(grid_for(c, lo_count)), dim3(kBlock), 0, cur_stream(c), slot->lo,
+                                         lo_count, dev_arg(c->hf, base_mont), dev_arg(c->hf, first)));
     if (hi_count) {
         HIP_TRY(hipMalloc((void**)&slot->hi, hi_count * 32));
         const H256 b1024 = c->hf.pow_u64(base_mont, 1024);
@@ -398,7 +401,7 @@ int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scal
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(cur_stream(c)));
-    slot->base = base_mont; slot->log_n = log_n; slot->scaled = scaled; slot->stamp = ++c->coset_clock;
+    slot->base = base_mont; slot->log_n = log_n; slot->scaled = scaled; slot->direct = direct; slot->stamp = ++c->coset_clock;
     *lo = slot->lo;
     *hi = slot->hi;
     return ACX_OK;
@@ -455,7 +458,11 @@ inline int r4_pick_lg(int lp, int want) {      // largest compiled LG <= want, o
 
 // In-place batched NTT on dev-format data.  Caller holds ctx->mu.
 //   forward: X[k] = sum_i x[i] (shift * omega^k)^i      inverse: undoes it.
-int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inverse, const H256* shift_mont) {
+// post_mont (inverse transforms without a coset shift only): the coefficients are multiplied by post^i on the way out --
+// "interpolate, then move to the coset post*<omega>" in one closing multiplication (the h(x) pipeline).  Returns
+// ACX_ERR_UNSUPPORTED when this size has no such fused form; the caller then takes the two-step route.
+int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inverse, const H256* shift_mont,
+                   const H256* post_mont = nullptr) {
     if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
     if (batch == 0) return ACX_OK;
     const HostField& hf = c->hf;
@@ -512,14 +519,19 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         }
         scratch = buf;
     }
-    uint4 *sc_lo = nullptr, *sc_hi = nullptr;
-    if (shift_mont) {
-        const H256 base = inverse ? hf.inv(*shift_mont) : *shift_mont;
-        ACX_TRY(get_coset_tables(c, base, log_n, inverse ? 1 : 0, &sc_lo, &sc_hi));
-    }
     // the r4 kernel can finish with a plain reduction: 1/N of an inverse transform is folded into the last
     // inter-pass twiddle table
     const bool fold_scale = r4 && inverse && !shift_mont && P >= 2;
+    // closing coset factor from ONE direct table (one product per element instead of two) where it fits
+    const bool direct_coset = r4 && inverse && (shift_mont || post_mont) && log_n <= std::max<uint32_t>(cfg.direct_tw, 16);
+    if (post_mont && (!inverse || shift_mont || !direct_coset)) return fail(ACX_ERR_UNSUPPORTED, "no fused post-scale for this transform");
+    uint4 *sc_lo = nullptr, *sc_hi = nullptr;
+    if (shift_mont) {
+        const H256 base = inverse ? hf.inv(*shift_mont) : *shift_mont;
+        ACX_TRY(get_coset_tables(c, base, log_n, inverse ? 1 : 0, &sc_lo, &sc_hi, direct_coset ? 1 : 0));
+    } else if (post_mont) {
+        ACX_TRY(get_coset_tables(c, *post_mont, log_n, fold_scale ? 0 : 1, &sc_lo, &sc_hi, 1));
+    }
     for (int p = 0; p < P; ++p) {
         NttPass Q;
         std::memset(&Q, 0, sizeof(Q));
@@ -610,6 +622,7 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
             Q.scale = dev_arg(hf, s);
             Q.scale_mode = (inverse && shift_mont) ? 2 : 1;
             if (r4 && Q.scale_mode == 1 && (!inverse || fold_scale)) Q.scale_mode = 0;   // nothing left to multiply by
+            if (direct_coset) Q.scale_mode = 3;                                           // one product from the direct table
         }
         Q.stride_t_in_hi = Q.stride_t_in;      // single stride in the transform direction (split = 0)
         Q.stride_t_out_hi = Q.stride_t_out;
@@ -1515,13 +1528,19 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
     uint4* keep = d + 6 * N;                                          // dots (3N) + kept L0, R0 (2N)
     HIP_TRY(hipMemsetAsync(d, 0, 3 * N * 32, cur_stream(c)));  // rows n..N-1 are the zero padding
     ACX_TRY(launch_residual(r, d_w, 0, d_result, nullptr, d, N));
-    // evaluations on <omega> -> coefficients of L0, R0, O0
-    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr));
     const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
-    if (zk) HIP_TRY(hipMemcpyAsync(keep, d, 2 * N * 32, hipMemcpyDeviceToDevice, cur_stream(c)));
-    // coset evaluations, shift = multiplicative generator g (g^N != 1)
+    // coset: shift = multiplicative generator g (g^N != 1)
     const H256 g = hf.generator();
-    ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, &g));
+    // evaluations on <omega> -> coefficients of L0, R0, O0 -> evaluations on g<omega>.  Without the zero-knowledge terms
+    // nobody needs the plain coefficients, so the factor g^i rides on the inverse transform's closing multiplication.
+    int fused = zk ? ACX_ERR_UNSUPPORTED : ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr, &g);
+    if (fused == ACX_OK) {
+        ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, nullptr));
+    } else {
+        ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr));
+        if (zk) HIP_TRY(hipMemcpyAsync(keep, d, 2 * N * 32, hipMemcpyDeviceToDevice, cur_stream(c)));
+        ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, &g));
+    }
     const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
     DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d,
                                          (const uint4*)(d + 2 * N), (const uint4*)(d + 4 * N), d_h, N, dev_arg(hf, zinv)));

@@ -360,7 +360,7 @@ struct NttPass {
     u32 n_outer;
     u32 tw_mode;           // 0 none, 1 direct table index (I*K) >> tw_shift, 2 two-level on (I*K) & tw_mask
     u32 tw_shift;
-    u32 scale_mode;        // 0 none, 1 multiply by `scale`, 2 scale * g^(element index) via sc_lo/sc_hi
+    u32 scale_mode;        // 0 none, 1 multiply by `scale`, 2 scale * g^(element index) via sc_lo/sc_hi, 3 (k_ntt_r4) g^(index) from the direct table sc_lo
     u32 scale_on_load;     // coset pre-multiplication of a forward transform (first pass)
     u32 pad;
     u64 tw_mask;
