@@ -232,6 +232,17 @@ __device__ __forceinline__ Fe fe_sub_lazy(const Fe& a, const Fe& b) {
     return s;
 }
 
+// a - b + FAT for a "fat" limb form of a multiple of p (P4FAT, P8FAT): borrow-free as long as every limb of b is at most
+// the matching limb of FAT.  P8FAT takes an UNCARRIED sum of two strict values as b (limbs <= 2^30 - 2, value < 4p).
+template <const u32 (&FAT)[kLimbs], bool CARRY = true>
+__device__ __forceinline__ Fe fe_sub_fat(const Fe& a, const Fe& b) {
+    Fe s;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) s.l[k] = a.l[k] + FAT[k] - b.l[k];
+    if (CARRY) fe_carry_loose(s);
+    return s;
+}
+
 // ---- deferred reduction: sum of raw limb products, one Montgomery reduction per sum --------------
 // Column accumulators of the schoolbook product: c[k] = sum over terms of sum_{i+j=k} a_i b_j.
 // Each v_mad_u64_u32 adds straight into its column (no carry handling at all).  With limbs

@@ -204,9 +204,10 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
         const Fe a1 = fe_add_lazy<false>(x[2], x[3]), s1 = fe_sub_lazy<F, false>(x[2], x[3]);
         x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
         if (!(R == 1 && odd)) {
-            const Fe t2 = fe_reduce_loose<F>(x[2]);
+            // pair (0,2): w = 1 and x[2] is the uncarried sum of two strict values: it is subtracted as it is, against
+            // the fat form of 8p (value grows by 8p once per pass: 12p after this round, < 64p after 12 stages)
             const Fe t3 = fe_mul<F>(x[3], fe_load_limbs(P.sub_tw, (u64)(S >> 2)));
-            const Fe b0 = fe_add_lazy(x[0], t2), d0 = fe_sub_lazy<F>(x[0], t2);
+            const Fe b0 = fe_add_lazy(x[0], x[2]), d0 = fe_sub_fat<F::P8FAT>(x[0], x[2]);
             const Fe b1 = fe_add_lazy(x[1], t3), d1 = fe_sub_lazy<F>(x[1], t3);
             x[0] = b0; x[2] = d0; x[1] = b1; x[3] = d1;
         }
