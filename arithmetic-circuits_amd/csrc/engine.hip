@@ -95,6 +95,7 @@ struct acx_ctx {
     std::map<std::tuple<uint32_t, uint64_t, int, uint32_t>, uint4*> tw_scaled;   // (log_m, count, inverse, log_n of folded 1/N)
     std::map<std::pair<uint32_t, int>, uint4*> tw_limbs;  // (log_m, inverse) -> omega_M^j, j < M/2, limb form (k_ntt_r4)
     NttCfg ntt;
+    bool small_coeff = true;                               // use the small-coefficient SELL form where a matrix allows it
     uint4* ntt_scratch = nullptr;                          // ping-pong buffer of the multi-pass NTT
     size_t ntt_scratch_bytes = 0;
     struct CosetTables {                                   // g^j (j < 1024), g^(1024 j) for one (g, log_n, scaled)
@@ -151,6 +152,7 @@ struct acx_r1cs {
     DevMatrix M[3];
     DevMatrix T[3];        // CSC, built lazily for acx_qap_columns
     bool unit_c = false;   // every stored C value is 1: the kernel never reads C's value stream
+    uint32_t small = 0;    // bit k: every coefficient of matrix k's SELL rows is small (|c| <= 2^27): no value stream
     // SELL-64 layout used by the residual kernel (kernels.hip.h)
     u32* sell_ofs[3] = {nullptr, nullptr, nullptr};
     uint2* sell_tail[3] = {nullptr, nullptr, nullptr};
@@ -753,9 +755,13 @@ SellSystem sell_system(const acx_r1cs* r, const uint4* d_w, const ResidualOut& o
     S.w = d_w;
     S.n_slices = r->n_slices;
     S.unit_c = r->unit_c ? 1u : 0u;
+    S.small = r->small;
     S.out = out;
     return S;
 }
+
+// the launch can use the instance specialised for compiled programs (small A and B, unit C)
+inline bool sell_spec(const acx_r1cs* r) { return (r->small & 3u) == 3u && r->unit_c; }
 
 inline unsigned sell_grid_x(uint32_t n_slices) {
     const uint32_t tiles = (n_slices + 3) / 4;
@@ -786,8 +792,13 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
     const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset};
     const SellSystem S = sell_system(r, d_w, out);
     const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, cur_stream(c),
-                                         (const SellSystem*)nullptr, S));
+    if (sell_spec(r)) {
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 1>), grid, dim3(kBlock), 0, cur_stream(c),
+                                             (const SellSystem*)nullptr, S));
+    } else {
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 0>), grid, dim3(kBlock), 0, cur_stream(c),
+                                             (const SellSystem*)nullptr, S));
+    }
     HIP_TRY(hipGetLastError());
     return launch_long_rows(r, d_w, out);
 }
@@ -838,16 +849,44 @@ int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
         const uint64_t slots = ofs[n_slices];
         HIP_TRY(hipMalloc((void**)&r->sell_ofs[k], ofs.size() * 4));
         HIP_TRY(hipMalloc((void**)&r->sell_tail[k], std::max<uint64_t>(slots, 1) * kSlice * 8));
-        HIP_TRY(hipMalloc((void**)&r->sell_val[k], std::max<uint64_t>(slots, 1) * kSlice * 32));
+        const bool small = (r->small >> k) & 1u;
+        if (!small) HIP_TRY(hipMalloc((void**)&r->sell_val[k], std::max<uint64_t>(slots, 1) * kSlice * 32));
         HIP_TRY(hipMemcpyAsync(r->sell_ofs[k], ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
         HIP_TRY(hipStreamSynchronize(cur_stream(c)));   // ofs is reused by the next matrix
         const CsrDev M{r->M[k].ptr, r->M[k].idx, r->M[k].val};
-        hipLaunchKernelGGL(k_build_sell, dim3((n_slices + 3) / 4), dim3(kBlock), 0, cur_stream(c), M, (const u32*)r->perm,
-                           (const u32*)r->sell_ofs[k], n_slices, r->sell_tail[k], r->sell_val[k]);
-        HIP_TRY(hipGetLastError());
+        if (small) {
+            HIP_TRY(hipMemsetAsync(cur_err(c), 0, 4, cur_stream(c)));
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_build_sell_small<F>), dim3((n_slices + 3) / 4), dim3(kBlock), 0, cur_stream(c), M,
+                                                 (const u32*)r->perm, (const u32*)r->sell_ofs[k], n_slices, r->sell_tail[k], cur_err(c)));
+            HIP_TRY(hipGetLastError());
+            uint32_t bad = 0;
+            HIP_TRY(hipMemcpyAsync(&bad, cur_err(c), 4, hipMemcpyDeviceToHost, cur_stream(c)));
+            HIP_TRY(hipStreamSynchronize(cur_stream(c)));
+            if (bad) return fail(ACX_ERR_HIP, "small-coefficient classification disagrees with the device");
+        } else {
+            hipLaunchKernelGGL(k_build_sell, dim3((n_slices + 3) / 4), dim3(kBlock), 0, cur_stream(c), M, (const u32*)r->perm,
+                               (const u32*)r->sell_ofs[k], n_slices, r->sell_tail[k], r->sell_val[k]);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     return ACX_OK;
+}
+
+// canonical value v with v <= 2^27 or p - v <= 2^27 (kSmallCoeffMax)
+bool is_small_coeff(const HostField& hf, const acx_fr& f) {
+    H256 v;
+    std::memcpy(v.l, f.b, 32);
+    if ((v.l[1] | v.l[2] | v.l[3]) == 0 && v.l[0] <= (uint64_t)kSmallCoeffMax) return true;
+    const H256& p = hf.modulus();
+    uint64_t d[4];
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned __int128 t = (unsigned __int128)p.l[i] - v.l[i] - (uint64_t)borrow;
+        d[i] = (uint64_t)t;
+        borrow = (t >> 64) & 1;
+    }
+    return borrow == 0 && (d[1] | d[2] | d[3]) == 0 && d[0] <= (uint64_t)kSmallCoeffMax;
 }
 
 int read_h256(const acx_fr* f, const HostField& hf, H256& mont) {
@@ -983,6 +1022,18 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
                 for (size_t e = 0; e < val.size() && unit; ++e) unit = std::memcmp(val[e].b, one32, 32) == 0;
                 r->unit_c = unit;
             }
+            // small-coefficient form (kernels.hip.h sell_dot_small): every entry of the rows this matrix keeps in SELL
+            // is c or p - c with c <= 2^27.  Rows longer than the SELL cut-over go through the CSR kernel whatever
+            // they hold (Split gates: powers of two up to 2^255), so they do not count.
+            if (rc == ACX_OK && ctx->small_coeff && !(k == 2 && r->unit_c)) {
+                bool small = !val.empty();
+                for (uint64_t i = 0; i < n && small; ++i) {
+                    const uint32_t e0 = rowptr[i], e1 = rowptr[i + 1];
+                    if (e1 - e0 > (uint32_t)kSellMaxLen) continue;
+                    for (uint32_t e = e0; e < e1 && small; ++e) small = is_small_coeff(ctx->hf, val[e]);
+                }
+                if (small) r->small |= 1u << k;
+            }
             if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, col, val.data(), true, r->M[k]);
         }
         if (rc == ACX_OK) rc = build_sell(r, rowptrs);
@@ -1097,6 +1148,7 @@ int acx_ctx_create(int field, int device_id, acx_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->hf = field == ACX_FIELD_BN254_FR ? HostField::make<Bn254Fr>() : HostField::make<Bls12381Fr>();
     c->ntt = ntt_cfg_from_env();
+    if (const char* e = std::getenv("ACX_R1CS_SMALL")) c->small_coeff = std::atoi(e) != 0;   // development A/B switch
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&c->d_result, 16) == hipSuccess && hipMalloc((void**)&c->d_err, 4) == hipSuccess;
     for (auto& ln : c->lanes)
@@ -1389,6 +1441,14 @@ int acx_r1cs_dims(const acx_r1cs* r, uint64_t* n, uint64_t* m, uint32_t* log_n, 
     if (m) *m = r->m;
     if (log_n) *log_n = r->log_n;
     if (nnz) for (int k = 0; k < 3; ++k) nnz[k] = r->M[k].nnz;
+    return ACX_OK;
+}
+
+int acx_r1cs_format(const acx_r1cs* r, uint32_t* small_mask, uint32_t* unit_c, uint64_t* n_long) {
+    if (!r) return fail(ACX_ERR_INVALID_ARG, "null r1cs");
+    if (small_mask) *small_mask = r->small;
+    if (unit_c) *unit_c = r->unit_c ? 1u : 0u;
+    if (n_long) *n_long = r->n_long;
     return ACX_OK;
 }
 
@@ -1948,8 +2008,15 @@ int acx_batch_verify_dev(acx_batch* b) {
     HIP_TRY(hipSetDevice(c->device));
     if (b->max_slices) {
         const dim3 grid(sell_grid_x(b->max_slices), (unsigned)b->systems.size(), 1);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F>), grid, dim3(kBlock), 0, cur_stream(c),
-                                             (const SellSystem*)b->d_systems, SellSystem{}));
+        bool spec = true;
+        for (const acx_r1cs* r : b->systems) spec = spec && sell_spec(r);
+        if (spec) {
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 1>), grid, dim3(kBlock), 0, cur_stream(c),
+                                                 (const SellSystem*)b->d_systems, SellSystem{}));
+        } else {
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 0>), grid, dim3(kBlock), 0, cur_stream(c),
+                                                 (const SellSystem*)b->d_systems, SellSystem{}));
+        }
         HIP_TRY(hipGetLastError());
     }
     for (size_t i = 0; i < b->systems.size(); ++i)

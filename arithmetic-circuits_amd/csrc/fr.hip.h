@@ -308,6 +308,41 @@ __device__ __forceinline__ Fe wide_reduce(const Wide& w) {
     return r;
 }
 
+// ---- small-coefficient dot products ---------------------------------------------------------------
+// A constraint matrix compiled from a program (src/Circuit/Expr.hs:256-305) carries coefficients +-1, +-2 and small
+// program constants.  For |c| <= kSmallCoeffMax the term c * x needs no Montgomery product: x is already a Montgomery
+// residue and c * (w R) = (c w) R, so a row's dot product is nine signed columns s[k] += c * x_k (one v_mad_i64_i32
+// each) followed by ONE exact reduction of the signed 9-column sum S (|S| < 2^59 * 2^232):
+//   q  = floor(S / p - 1/2) estimated in f64 from columns 8 and 7 (the rest is < 2^-20 p; f64 rounding < 2^-12), so that
+//        S - q p lies in (0.49 p, 1.51 p);
+//   r  = S - q p column by column with q = qh * 2^29 + ql (18 multiplier instructions), one signed carry chain.
+// Result lazy (normalised limbs, value in [0, 2p)).  At most kWideTerms terms per sum.
+constexpr i32 kSmallCoeffMax = 1 << 27;
+using i64 = int64_t;
+
+template <class F>
+__device__ __forceinline__ Fe small_reduce(const i64 (&s)[kLimbs]) {
+    const double top = __builtin_fma((double)s[kLimbs - 1], 536870912.0, (double)s[kLimbs - 2]);   // S ~ top * 2^203
+    const double qd = __builtin_floor(__builtin_fma(top, F::PINV203, -0.5));
+    const double qhd = __builtin_floor(qd * (1.0 / 536870912.0));
+    const i32 qh = (i32)qhd;                                        // |q| < 2^41: qh in (-2^12, 2^12)
+    const i32 ql = (i32)__builtin_fma(qhd, -536870912.0, qd);       // [0, 2^29)
+    Fe r;
+    i64 t = 0;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+        t += s[k] - (i64)ql * (i64)(i32)F::P[k];
+        if (k > 0) t -= (i64)qh * (i64)(i32)F::P[k - 1];
+        if (k < kLimbs - 1) {
+            r.l[k] = (u32)t & kLimbMask;
+            t >>= kLimbBits;                                        // arithmetic: borrows propagate as -1
+        }
+    }
+    t -= ((i64)qh * (i64)(i32)F::P[kLimbs - 1]) << kLimbBits;       // column 9 of q p; the sum is < 2p, so it cancels
+    r.l[kLimbs - 1] = (u32)t;
+    return r;
+}
+
 // lazy [0,2p) -> canonical residue [0,p) of the same Montgomery value
 template <class F>
 __device__ __forceinline__ Fe fe_reduce(const Fe& a) {

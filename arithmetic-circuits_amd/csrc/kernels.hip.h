@@ -115,6 +115,46 @@ __global__ __launch_bounds__(kBlock) void k_build_sell(CsrDev M, const u32* __re
     }
 }
 
+// The same for a matrix whose SELL rows carry only small coefficients (|c| <= kSmallCoeffMax, src/Circuit/Expr.hs
+// compiles programs to +-1, +-2 and small constants): the slot is {signed coefficient, column} and there is no value
+// stream at all -- 8 bytes per entry instead of 40.  The coefficient is recovered from the Montgomery CSR value.
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_build_sell_small(CsrDev M, const u32* __restrict__ perm,
+                                                            const u32* __restrict__ slice_ofs, u32 n_slices,
+                                                            uint2* __restrict__ tail, u32* __restrict__ err) {
+    const u32 slice = blockIdx.x * (kBlock / kSlice) + (threadIdx.x / kSlice);
+    const u32 lane = threadIdx.x % kSlice;
+    if (slice >= n_slices) return;
+    const u32 q0 = slice_ofs[slice], q1 = slice_ofs[slice + 1];
+    const u32 row = perm[slice * kSlice + lane];
+    u32 e0 = 0, len = 0;
+    if (row != kNoRow) { e0 = M.rowptr[row]; len = M.rowptr[row + 1] - e0; }
+    for (u32 q = q0; q < q1; ++q) {
+        const u32 j = q - q0;
+        i32 cf = 0;
+        u32 c = kNoRow;
+        if (j < len) {
+            const Fe v = fe_from_mont<F>(fe_load(M.val + 2 * (u64)(e0 + j)));   // canonical
+            u32 hi = 0, hin = 0;
+            Fe neg;                                              // p - v
+            i32 br = 0;
+#pragma unroll
+            for (int k = 0; k < kLimbs; ++k) {
+                const i32 t = (i32)F::P[k] - (i32)v.l[k] + br;
+                neg.l[k] = (u32)t & kLimbMask;
+                br = t >> kLimbBits;
+            }
+#pragma unroll
+            for (int k = 1; k < kLimbs; ++k) { hi |= v.l[k]; hin |= neg.l[k]; }
+            if (hi == 0 && v.l[0] <= (u32)kSmallCoeffMax) cf = (i32)v.l[0];
+            else if (hin == 0 && neg.l[0] <= (u32)kSmallCoeffMax) cf = -(i32)neg.l[0];
+            else atomicAdd(err, 1u);                             // the host classified this matrix as small: cannot happen
+            c = M.col[e0 + j];
+        }
+        tail[(u64)q * kSlice + lane] = make_uint2((u32)cf, c);
+    }
+}
+
 // Pointers that reach a kernel through a descriptor in memory (SellSystem) have no known address
 // space and hipcc emits flat_load for them (counted against lgkmcnt as well as vmcnt, and split into
 // odd 4/16/12-byte pieces for the 32-byte gathers).  These helpers pin the global address space
@@ -196,6 +236,40 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
     return wide_reduce<F>(wide);
 }
 
+// <M_row, w> for a small-coefficient matrix: nine signed columns, one v_mad_i64_i32 per limb and entry, one exact
+// reduction per row (small_reduce).  The register budget the deferred-reduction path spends on its 17 64-bit columns
+// pays here for a deeper pipeline: the column word of slot q+2 and the witness gather of slot q+1 are in flight while
+// slot q is accumulated.
+template <class F>
+__device__ __forceinline__ Fe sell_dot_small(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane) {
+    const u32 q0 = gload(M.slice_ofs + slice), q1 = gload(M.slice_ofs + slice + 1);   // wave-uniform
+    static_assert(kSellMaxLen <= kWideTerms, "column bound of small_reduce");
+    if (q0 == q1) return fe_zero();
+    i64 acc[kLimbs];
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) acc[k] = 0;
+    uint2 t = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
+    uint2 tn = t;
+    if (q0 + 1 < q1) tn = nt_load(&M.tail[(u64)(q0 + 1) * kSlice + lane]);
+    const uint4* px = w + 2 * (u64)(t.y == kNoRow ? 0u : t.y);
+    uint4 xlo = gload(px), xhi = gload(px + 1);
+    for (u32 q = q0; q < q1; ++q) {
+        const i32 cf = t.y == kNoRow ? 0 : (i32)t.x;
+        const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
+        if (q + 1 < q1) {
+            t = tn;
+            const uint4* pn = w + 2 * (u64)(t.y == kNoRow ? 0u : t.y);
+            xlo = gload(pn);
+            xhi = gload(pn + 1);
+            if (q + 2 < q1) tn = nt_load(&M.tail[(u64)(q + 2) * kSlice + lane]);
+        }
+        const Fe x = fe_unpack(xw);
+#pragma unroll
+        for (int k = 0; k < kLimbs; ++k) acc[k] += (i64)cf * (i64)(i32)x.l[k];
+    }
+    return small_reduce<F>(acc);
+}
+
 struct ResidualOut {
     unsigned long long* result;  // {n_bad, first_bad}
     uint4* residuals;            // [n] or null
@@ -240,6 +314,7 @@ struct SellSystem {
     const uint4* w;        // witness, dev format (32 bytes per element)
     u32 n_slices;
     u32 unit_c;
+    u32 small;             // bit k: matrix k (A, B, C) is stored in the small-coefficient form
     ResidualOut out;
 };
 
@@ -249,7 +324,9 @@ struct SellSystem {
 // so XCD x gets the contiguous tile range [x*T/8, (x+1)*T/8): the rows in flight on an XCD, and
 // the witness window they gather from, stay inside its private 4 MiB L2.  gridDim.x = tiles
 // rounded up to a multiple of 8.
-template <class F>
+// SPEC = 1: every system of the launch has small-coefficient A and B and a unit C (the shape of a compiled program);
+// the instance then carries none of the deferred-reduction path's registers.
+template <class F, int SPEC = 0>
 __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
     const SellSystem& S = systems != nullptr ? systems[blockIdx.y] : one;   // batched : single
     const u32 tiles = (S.n_slices + 3) / 4;
@@ -266,11 +343,12 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
     u32 row = kNoRow;
     if (slice < S.n_slices) {
         row = gload(S.perm + slice * kSlice + lane);
-        a = sell_dot<F, false>(S.A, S.w, slice, lane);
+        a = (SPEC == 1 || (S.small & 1u)) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
 #pragma unroll
         for (int i = 0; i < kLimbs; ++i) park[i][threadIdx.x] = a.l[i];
-        b = sell_dot<F, false>(S.B, S.w, slice, lane);
-        c = S.unit_c ? sell_dot<F, true>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
+        b = (SPEC == 1 || (S.small & 2u)) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
+        c = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
+            : (S.small & 4u) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
 #pragma unroll
         for (int i = 0; i < kLimbs; ++i) a.l[i] = park[i][threadIdx.x];
     }

@@ -151,6 +151,12 @@ class R1CS:
         except Exception:
             pass
 
+    def format(self) -> Tuple[int, bool, int]:
+        """(small-coefficient mask over A, B, C; unit C; rows on the CSR path): how the residual kernel stores the system."""
+        small, unit, n_long = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(self.ctx.lib.acx_r1cs_format(self._h, C.byref(small), C.byref(unit), C.byref(n_long)))
+        return small.value, bool(unit.value), n_long.value
+
     def export(self, matrix: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         rowptr = np.zeros(self.n + 1, dtype=np.uint32)
         col = np.zeros(self.nnz[matrix], dtype=np.uint32)

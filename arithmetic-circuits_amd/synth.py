@@ -60,6 +60,26 @@ def random_fr(count: int, seed: int, stream: int, field: str = "bn254") -> np.nd
     return out
 
 
+def small_fr(count: int, seed: int, stream: int, field: str = "bn254", bits: int = 16) -> np.ndarray:
+    """`count` coefficients of a compiled program's shape (src/Circuit/Expr.hs:256-305): +-c with 1 <= c <= 2^bits,
+    negative ones as p - c; (count,4) uint64 canonical."""
+    p = FIELDS[field][1]
+    idx = np.arange(count, dtype=np.uint64)
+    r = _stream(seed, stream * 4, idx)
+    mag = (r % np.uint64(1 << bits)) + np.uint64(1)
+    neg = ((r >> np.uint64(40)) & np.uint64(1)) == 1
+    out = np.zeros((count, 4), dtype=np.uint64)
+    out[:, 0] = mag
+    pl = [(p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    # p - c for c < 2^64: borrow only from limb 0 (p's low limb exceeds 2^bits for both fields)
+    assert pl[0] > (1 << bits)
+    with np.errstate(over="ignore"):
+        out[neg, 0] = np.uint64(pl[0]) - mag[neg]
+    for j in (1, 2, 3):
+        out[neg, j] = np.uint64(pl[j])
+    return out
+
+
 @dataclass
 class SynthCircuit:
     circuit: Circuit           # marshalled (host) circuit
@@ -77,7 +97,7 @@ class SynthCircuit:
 
 
 def mulgraph(n: int, n_in: int = 1024, k: int = 2, window: int = 4096, seed: int = 0xAC355,
-             field: str = "bn254") -> SynthCircuit:
+             field: str = "bn254", coeff: str = "random") -> SynthCircuit:
     if n < 1 or n_in < 1 or k < 1:
         raise ValueError("n, n_in, k must be positive")
     sides = 2 * n
@@ -97,10 +117,14 @@ def mulgraph(n: int, n_in: int = 1024, k: int = 2, window: int = 4096, seed: int
     aff_wires[:, 0] = use_mid.astype(np.uint32)          # 1 = IntermediateWire, 0 = InputWire
     aff_wires[:, 1] = np.where(use_mid, mid_index, inp_index).astype(np.uint32)
     # scalars: k coefficients per side, then one constant per side that has one
-    coeff = random_fr(sides * k, seed, 10, field)
     n_const = int(has_const.sum())
-    consts = random_fr(n_const, seed, 11, field)
-    scalars = np.concatenate([coeff, consts], axis=0)
+    if coeff == "random":          # uniform in [0, p)
+        coeffs, consts = random_fr(sides * k, seed, 10, field), random_fr(n_const, seed, 11, field)
+    elif coeff == "small":         # the shape of a compiled program: +-c, c <= 2^16
+        coeffs, consts = small_fr(sides * k, seed, 10, field), small_fr(n_const, seed, 11, field)
+    else:
+        raise ValueError("coeff must be 'random' or 'small'")
+    scalars = np.concatenate([coeffs, consts], axis=0)
     const_slot = np.cumsum(has_const) - 1 + sides * k       # scalar index of a side's constant
     # tokens per side: (k-1) ADDs [+1 ADD if const], k x (SMUL, VAR) [, CONST]
     #   pre-order of  Add(t1, Add(t2, ... Add(t_k, const)))   /   Add(t1, ... Add(t_{k-1}, t_k))

@@ -165,6 +165,41 @@ def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
             "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6, "roofline": _hbm(alg, us)}
 
 
+def bench_small_coeff(ctx, stream, field="bn254", copies=32, log_n=16, reps=50, prewarm=0.25):
+    """The same batched verification on systems of a compiled program's shape (src/Circuit/Expr.hs:256-305: coefficients
+    +-c with c <= 2^16 instead of uniform field elements): libacx stores such matrices as {coefficient, column} pairs and
+    the dot products need no 256-bit products.  Parity gate: the first system's residual vector under a corrupted witness
+    against the C oracle, every satisfying witness accepted."""
+    from oracle.c_oracle import COracle
+    orc = COracle(field)
+    n = 1 << log_n
+    systems, witnesses, alg, fmt = [], [], 0, None
+    for c in range(copies):
+        s = synth.mulgraph(n, seed=0x5AC355 + c, field=field, coeff="small")
+        r = s.circuit.to_r1cs(ctx)
+        w = s.witness()
+        if c == 0:
+            mats = s.rows()
+            w2 = w.copy()
+            w2[[3, 1500, r.m - 2], 0] ^= np.uint64(1)
+            want, nbad, first = orc.r1cs_residuals(n, r.m, *mats, w2, nthreads=os.cpu_count() or 1)
+            parity = bool(np.array_equal(r.residuals(w2), want) and r.verify(w2) == (False, nbad, first) and nbad > 0)
+            fmt = r.format()
+            alg = algorithmic_bytes(mats, n)[0] * copies
+        systems.append(r)
+        witnesses.append(to_dev(ctx, w))
+    res = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    batch = acx.Batch(ctx, systems, [w.data_ptr() for w in witnesses], res.data_ptr())
+    us = _timed(stream, batch.verify_dev, reps, prewarm)
+    ctx.sync()
+    parity = parity and int(res[0]) == 0
+    return {"workload": f"r1cs_verify: {copies} independent 2^{log_n}-constraint mulgraph systems per launch with coefficients +-c, c <= 2^16 "
+                        f"(compiled-program shape; {field} Fr)", "parity_vs_oracle": parity, "us_per_launch": us,
+            "constraints_per_s": copies * n / us * 1e6, "small_coefficient_matrices": fmt[0], "unit_c": fmt[1],
+            "algorithmic_bytes_as_8d": alg, "note": "8 bytes per entry are streamed instead of 40; not an HBM-roofline figure"}
+
+
 def bench_distributed(ctx, a, world, rank, dist):
     """configs[3] beside the headline (N > 1, or --force-dist on one GPU): the distributed four-step NTT at
     N = 2^24 (one all-to-all per transform) and the distributed h(x) pipeline on a 2^24-constraint block system
@@ -463,6 +498,7 @@ def main():
         if world == 1 and not a.no_ntt:
             out["ntt"] = bench_ntt(ctx, stream, a.field, prewarm=a.prewarm)
             out["qap_h"] = bench_qap_h(ctx, stream, a.field, prewarm=a.prewarm)
+            out["r1cs_small_coeff"] = bench_small_coeff(ctx, stream, a.field, copies=a.copies, log_n=a.logn, prewarm=a.prewarm)
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(sample, a.field)
         print(json.dumps(out))

@@ -171,6 +171,13 @@ int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const 
                   const acx_csr* C, acx_r1cs** out);
 void acx_r1cs_destroy(acx_r1cs* r);
 int acx_r1cs_dims(const acx_r1cs* r, uint64_t* n, uint64_t* m, uint32_t* log_n, uint64_t nnz[3]);
+/* How the residual kernel stores the system (introspection; results never depend on it).  small_mask bit k (A, B, C):
+ * every coefficient of matrix k's rows of <= 6 entries is c or p - c with c <= 2^27 -- the shape programs compile to
+ * (src/Circuit/Expr.hs:256-305: +-1, +-2, small constants) -- and the matrix is held as {coefficient, column} pairs of
+ * 8 bytes with no 32-byte value stream; a term is then nine multiply-adds instead of a 81-multiply product.
+ * unit_c: every C coefficient is 1 (src/QAP.hs:406-409: a Mul gate's output row).  n_long: rows with more than 6 entries
+ * in some matrix (Split gates), which take the CSR kernel.  Any pointer may be NULL. */
+int acx_r1cs_format(const acx_r1cs* r, uint32_t* small_mask, uint32_t* unit_c, uint64_t* n_long);
 /* Copy one matrix back as canonical CSR (caller sizes buffers from acx_r1cs_dims). */
 int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* col, acx_fr* val);
 

@@ -59,7 +59,7 @@ def bench_r1cs(ctx, stream, log_n, reps, copies):
     n = 1 << log_n
     systems = []
     for c in range(copies):
-        s = synth.mulgraph(n, seed=0xAC355 + c, n_in=N_IN, window=WINDOW)
+        s = synth.mulgraph(n, seed=0xAC355 + c, n_in=N_IN, window=WINDOW, coeff=COEFF)
         mats = s.rows()
         r = s.circuit.to_r1cs(ctx)
         w = to_dev(ctx, s.witness())
@@ -78,7 +78,7 @@ def bench_r1cs(ctx, stream, log_n, reps, copies):
     us = time_stream(stream, fn, reps * copies)
     ctx.sync()
     assert int(res[0]) == 0 or os.environ.get("ACX_ABLATION"), "witness must verify"
-    print(f"r1cs n=2^{log_n} copies={copies}: {us:9.2f} us/launch  {n / us * 1e6:.3e} constraints/s  "
+    print(f"r1cs[{COEFF}, format {systems[0][0].format()}] n=2^{log_n} copies={copies}: {us:9.2f} us/launch  {n / us * 1e6:.3e} constraints/s  "
           f"alg {b / 1e6:.2f} MB -> {b / us * 1e-3:.1f} GB/s ({b / us * 1e-3 / 8000 * 100:.1f}% of 8 TB/s)  nnz={nnz} m_ref={m_ref}")
 
 
@@ -107,20 +107,21 @@ def bench_h(ctx, log_n):
     print(f"qap_h n=2^{log_n}: {dt * 1e3:9.2f} ms per call (host in/out, includes H2D of w and D2H of h)")
 
 
-N_IN, WINDOW = 1024, 4096
+N_IN, WINDOW, COEFF = 1024, 4096, "random"
 
 
 def main():
-    global N_IN, WINDOW
+    global N_IN, WINDOW, COEFF
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-in", type=int, default=1024)
     ap.add_argument("--window", type=int, default=4096)
+    ap.add_argument("--coeff", default="random", choices=["random", "small"])
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--logn", type=int, nargs="*", default=[16, 20])
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--copies", type=int, default=4)
     a = ap.parse_args()
-    N_IN, WINDOW = a.n_in, a.window
+    N_IN, WINDOW, COEFF = a.n_in, a.window, a.coeff
     ctx = acx.Context("bn254", 0)
     stream = torch.cuda.ExternalStream(ctx.stream)
     for ln in a.logn:
