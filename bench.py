@@ -91,6 +91,21 @@ def _from_dev(ctx, t, count):
     return out.cpu().numpy().view(np.uint64).reshape(-1, 4)[:count]
 
 
+def _valu_issue(key, count_field, us, workload):
+    """VALU-issue fraction of a kernel: SQ_INSTS_VALU (wave instructions per launch, from the committed rocprofv3 --pmc
+    pass of the same workload) / 1024 SIMDs / the measured multiplier issue rate, over the live launch time."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        if tr[key]["workload"] != workload:
+            return None
+        rate = tr["valu_rate"]
+        bound_us = tr[key][count_field] / rate["simds"] / rate["wave_insts_per_s_per_simd"] * 1e6
+        return {"wave_insts": tr[key][count_field], "issue_bound_us": bound_us, "frac": bound_us / us,
+                "source": "profiles/r02_bench.txt, profiles/r01_valu_rates.txt"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def _hbm(alg_bytes, us, **extra):
     d = {"bound": "hbm", "achieved": alg_bytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": alg_bytes / us * 1e-3 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes}
@@ -130,10 +145,11 @@ def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=40, prewarm=0.25, batch
     us_b = _timed(stream, many, 6, prewarm) / batch
     alg = 128 * n      # two reads + two writes of every 32-byte element (two-pass four-step)
     note = ("VALU-bound: ~10 Montgomery products (171 v_mad_u64_u32 each) per element; the HBM fraction is what "
-            "SURVEY.md 8(d) asks to be quoted, the VALU issue model is in profiles/r02_ntt_*.txt")
+            "SURVEY.md 8(d) asks to be quoted, valu_issue is the fraction of the integer-issue bound (profiles/r02_ntt.txt)")
     return {"workload": f"NTT N=2^{log_n} ({field} Fr), alternating inverse/forward on a fixed vector, acx::k_ntt_r4",
             "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6,
-            "roofline": _hbm(alg, us, note=note),
+            "roofline": _hbm(alg, us, note=note, valu_issue=_valu_issue("acx::k_ntt_r4", "valu_wave_insts_per_transform", us,
+                                                                        {"field": field, "logn": log_n})),
             "batch": {"transforms": batch, "us_per_transform": us_b, "field_ops_per_s": ops / us_b * 1e6,
                       "roofline": _hbm(alg, us_b)}}
 
@@ -493,6 +509,7 @@ def main():
             if tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr["source"]
+                out["roofline"]["valu_issue"] = _valu_issue("acx::k_r1cs_sell", "valu_wave_insts_per_launch", kernel_us, tr["workload"])
         except (OSError, KeyError, ValueError):
             pass
         if world == 1 and not a.no_ntt:
