@@ -27,8 +27,15 @@ def main(seeds):
                 rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
                 col = np.concatenate([np.sort(rs.choice(m, size=l, replace=False)) for l in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.uint32)
                 nnz = int(rowptr[-1])
+                small = rnd.random() < 0.4          # the small-coefficient form of a matrix (|c| <= 2^27), boundary included
                 if k == 2 and unit_c:
                     vals = [1] * nnz
+                elif small:
+                    B = 1 << 27
+                    vals = [(c if rnd.random() < 0.5 else (p - c) % p) for c in
+                            (rnd.choice([0, 1, 2, B, B - 1, rnd.randrange(B), rnd.randrange(256)]) for _ in range(nnz))]
+                    if rnd.random() < 0.3 and nnz:   # one entry just over the boundary: must fall back to the value stream
+                        vals[rnd.randrange(nnz)] = rnd.choice([B + 1, p - B - 1])
                 else:
                     vals = [rnd.choice([0, 1, p - 1, p - 2]) if rnd.random() < 0.2 else rnd.randrange(p) for _ in range(nnz)]
                 mats.append((rowptr, col, acx.ints_to_fr(vals) if nnz else np.zeros((0, 4), dtype=np.uint64)))
