@@ -317,10 +317,12 @@ def test_concurrent_callers_overlap(request, acx):
             assert r.verify(w)[0]
 
     burst(0)                                          # warm-up: arenas, clocks
-    t0 = time.perf_counter()
-    for k in range(nthreads):
-        burst(k)
-    serial = time.perf_counter() - t0
+    serial = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for k in range(nthreads):
+            burst(k)
+        serial = min(serial, time.perf_counter() - t0)
     errs = []
 
     def worker(k):
@@ -333,12 +335,14 @@ def test_concurrent_callers_overlap(request, acx):
         except Exception as e:                        # surfaced below: assertions inside threads are otherwise lost
             errs.append(e)
 
-    for _ in range(2):                                # second round: every lane's arena exists
+    parallel = float("inf")
+    for i in range(4):                                # from the second round on every lane's arena exists; best of three
         ts = [threading.Thread(target=worker, args=(k,)) for k in range(nthreads)]
         t0 = time.perf_counter()
         [t.start() for t in ts]
         [t.join() for t in ts]
-        parallel = time.perf_counter() - t0
+        if i > 0:
+            parallel = min(parallel, time.perf_counter() - t0)
     assert not errs, errs
     # the parallel round also carried a residual vector and an h(x); even so it must beat the serial verifies
     assert serial / parallel > 1.5, (serial, parallel)
