@@ -1586,7 +1586,8 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
     if ((int)r->log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
     const uint64_t N = 1ull << r->log_n;
     uint4* keep = d + 6 * N;                                          // dots (3N) + kept L0, R0 (2N)
-    HIP_TRY(hipMemsetAsync(d, 0, 3 * N * 32, cur_stream(c)));  // rows n..N-1 are the zero padding
+    if (N > r->n)                                                    // rows n..N-1 are the zero padding
+        for (int k = 0; k < 3; ++k) HIP_TRY(hipMemsetAsync(d + 2 * ((uint64_t)k * N + r->n), 0, (N - r->n) * 32, cur_stream(c)));
     ACX_TRY(launch_residual(r, d_w, 0, d_result, nullptr, d, N));
     const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
     // coset: shift = multiplicative generator g (g^N != 1)
@@ -1603,7 +1604,7 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
     }
     const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
     DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d,
-                                         (const uint4*)(d + 2 * N), (const uint4*)(d + 4 * N), d_h, N, dev_arg(hf, zinv)));
+                                         (const uint4*)(d + 2 * N), (const uint4*)(d + 4 * N), d_h, N, dev_arg(hf, zinv), zk ? 0u : 1u));
     ACX_TRY(ntt_dev_locked(c, d_h, r->log_n, 1, 1, &g));
     if (zk) {
         // (L0+d1 T)(R0+d2 T) - (O0+d3 T) = T * (h0 + d1 R0 + d2 L0 + d1 d2 T - d3),  T = x^N - 1
@@ -1615,8 +1616,6 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
                                dev_arg(hf, dl[0]), dev_arg(hf, dl[1]));
             hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, cur_stream(c), d_h, N, dev_arg(hf, hf.add(d12, dl[2])), dev_arg(hf, d12));
         });
-    } else {
-        HIP_TRY(hipMemsetAsync(d_h + 2 * N, 0, 32, cur_stream(c)));
     }
     HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -1773,7 +1772,7 @@ int acx_qap_pointwise_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_
     CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d_a,
-                                         (const uint4*)d_b, (const uint4*)d_c, (uint4*)d_out, count, dev_arg(hf, hf.inv(z))));
+                                         (const uint4*)d_b, (const uint4*)d_c, (uint4*)d_out, count, dev_arg(hf, hf.inv(z)), 0u));
     HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

@@ -547,8 +547,10 @@ __global__ __launch_bounds__(kBlock) void k_ntt_tile(NttPass P) {
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_pointwise_h(const uint4* __restrict__ a, const uint4* __restrict__ b,
                                                        const uint4* __restrict__ c, uint4* __restrict__ out, u64 n,
-                                                       FeArg zinv_arg) {
+                                                       FeArg zinv_arg, u32 zero_top) {
     const Fe zinv = fe_from_arg(zinv_arg);
+    if (zero_top && blockIdx.x == 0 && threadIdx.x == 0) fe_store(out + 2 * n, fe_zero());   // h has N+1 coefficients; the
+                                                                                             // transform that follows leaves it alone
     for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
         const Fe t = fe_sub<F>(fe_mul<F>(fe_load(a + 2 * i), fe_load(b + 2 * i)), fe_load(c + 2 * i));
         fe_store(out + 2 * i, fe_mul<F>(t, zinv));
