@@ -272,9 +272,10 @@ class DistributedNTT:
     every link busy); a pipeline of transforms (the 7 NTTs of h(x)) alternates the two layouts, so nothing is
     ever re-ordered in between."""
 
-    def __init__(self, log_n: int, ops: LocalOps, group=None, log_r: Optional[int] = None):
+    def __init__(self, log_n: int, ops: LocalOps, group=None, log_r: Optional[int] = None, force_collective: bool = False):
         self.group = group
         self.world, self.rank = _world(group)
+        self.force_collective = force_collective        # issue the collective even with one rank (RCCL smoke test on one GPU)
         self.log_n = log_n
         self.log_r = log_r if log_r is not None else log_n // 2
         self.log_c = log_n - self.log_r
@@ -283,7 +284,7 @@ class DistributedNTT:
             raise ValueError("world size must divide both factors of N")
         self.local = (1 << log_n) // self.world
         self.ops = ops
-        self._send = self._recv = None
+        self._pool = []                                  # (send, recv) pairs, one per transform in flight
 
     # -- layout helpers (tests / single-rank users) ---------------------------------------------
     def cols_indices(self) -> np.ndarray:
@@ -297,37 +298,85 @@ class DistributedNTT:
         """Natural index k = k1 + k2*R of every element of this rank's ROWS block, in local order."""
         return cyclic_rows(self.log_n, self.log_r, self.world, self.rank)
 
-    def _buffers(self, like: torch.Tensor):
-        if self._send is None or self._send.device != like.device or self._send.dtype != like.dtype:
-            self._send = torch.empty((self.local, 4), dtype=like.dtype, device=like.device)
-            self._recv = torch.empty_like(self._send)
-        return self._send, self._recv
+    def _buffers(self, like: torch.Tensor, slot: int = 0):
+        while len(self._pool) <= slot:
+            self._pool.append(None)
+        pair = self._pool[slot]
+        if pair is None or pair[0].device != like.device or pair[0].dtype != like.dtype:
+            send = torch.empty((self.local, 4), dtype=like.dtype, device=like.device)
+            pair = self._pool[slot] = (send, torch.empty_like(send))
+        return pair
 
-    def _all_to_all(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
-            return send
-        if send.is_cuda and dist.get_backend(self.group) == "gloo":
-            # gloo has no CUDA all-to-all: stage through the host (test configurations with several ranks on one
-            # GPU; a real multi-GPU job uses the nccl = RCCL backend and never comes here)
-            torch.cuda.synchronize()
-            s = send.cpu()
-            r = torch.empty_like(s)
-            dist.all_to_all_single(r, s, group=self.group)
-            recv.copy_(r)
-            return recv
-        dist.all_to_all_single(recv, send, group=self.group)
-        return recv
+    def _exchanges(self) -> bool:
+        return self.world > 1 or self.force_collective
 
-    def _run(self, x: torch.Tensor, out: Optional[torch.Tensor], inverse: bool, shift: Optional[int]) -> torch.Tensor:
+    def overlapped(self, like: torch.Tensor) -> bool:
+        """True when begin() returns with the exchange still in flight: RCCL runs the collective on its own stream, so
+        the caller's next local step (another transform of the pipeline) overlaps it."""
+        return bool(like.is_cuda and self._exchanges() and dist.get_backend(self.group) == "nccl")
+
+    def stream_context(self):
+        """The HIP stream every step of a pipeline is issued on (libacx's own, for HipOps): collectives are ordered
+        against it.  Fenced against the caller's current stream on entry and exit, so tensors produced or consumed by
+        torch operations outside the block need no further care."""
+        import contextlib
+        ext = getattr(self.ops, "_ext", None)
+        if ext is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def fenced():
+            outer = torch.cuda.current_stream()
+            if outer.cuda_stream == ext.cuda_stream:
+                yield
+                return
+            ext.wait_stream(outer)
+            with torch.cuda.stream(ext):
+                yield
+            outer.wait_stream(ext)
+        return fenced()
+
+    def begin(self, x: torch.Tensor, inverse: bool, shift: Optional[int] = None, slot: int = 0):
+        """First local step of one transform and the START of its all-to-all (src/QAP.hs:512-525's transform, sharded).
+        Returns a token for finish().  Transforms in flight at the same time need different slots (buffer pairs)."""
         assert x.shape == (self.local, 4) and x.is_contiguous()
-        if out is None:
-            out = torch.empty_like(x)
-        send, recv = self._buffers(x)
+        send, recv = self._buffers(x, slot)
         a = (self.log_n, self.log_r, self.world, self.rank, inverse)
         self.ops.dist_step(x, send, *a, 0, shift)
-        got = self._all_to_all(send, recv)
+        work, got = None, send
+        if self._exchanges():
+            if self.overlapped(x):
+                # enqueued behind the local step on the current stream; returns at once, the copy engine / xGMI links
+                # work while the SIMDs run the next transform's local step
+                work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+                got = recv
+            elif x.is_cuda and dist.get_backend(self.group) == "gloo":
+                # gloo has no CUDA all-to-all: stage through the host (test configurations with several ranks on one
+                # GPU; a real multi-GPU job uses the nccl = RCCL backend and never comes here)
+                torch.cuda.synchronize()
+                sh = send.cpu()
+                rh = torch.empty_like(sh)
+                dist.all_to_all_single(rh, sh, group=self.group)
+                recv.copy_(rh)
+                got = recv
+            else:
+                dist.all_to_all_single(recv, send, group=self.group)
+                got = recv
+        return (work, got, a, shift)
+
+    def finish(self, token, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Wait (stream-side) for the exchange, then the second local step."""
+        work, got, a, shift = token
+        if work is not None:
+            work.wait()
+        if out is None:
+            out = torch.empty_like(got)
         self.ops.dist_step(got, out, *a, 1, shift)
         return out
+
+    def _run(self, x: torch.Tensor, out: Optional[torch.Tensor], inverse: bool, shift: Optional[int]) -> torch.Tensor:
+        with self.stream_context():
+            return self.finish(self.begin(x, inverse, shift), out)
 
     def forward(self, cols: torch.Tensor, out: Optional[torch.Tensor] = None, shift: Optional[int] = None) -> torch.Tensor:
         return self._run(cols, out, False, shift)
@@ -358,11 +407,20 @@ class DistributedQapH:
                           torch.empty((3 * L, 4), dtype=torch.int64, device=dev))
         dots, tmp = self._bufs
         verdict, first = self.sharded.dots(w, dots)                       # rows of padding give 0
-        for k in range(3):
-            nt.inverse(dots[k * L:(k + 1) * L], out=tmp[k * L:(k + 1) * L])
-        for k in range(3):
-            nt.forward(tmp[k * L:(k + 1) * L], out=dots[k * L:(k + 1) * L], shift=self.g)
-        nt.ops.pointwise_h(dots[:L], dots[L:2 * L], dots[2 * L:], tmp[:L], nt.log_n, self.g)
-        h = nt.inverse(tmp[:L], out=tmp[L:2 * L], shift=self.g)
+        part = lambda t, k: t[k * L:(k + 1) * L]
+        # Software pipeline over the three vectors: the exchange of vector k runs (on RCCL's stream) under the local
+        # steps of vector k+1, and a vector's forward transform starts as soon as its inverse one is complete -- of
+        # the seven all-to-alls only the last one has no local work to hide behind.  Without an overlapping backend
+        # (one rank, gloo) begin() completes the exchange itself and this is the plain sequence.
+        with nt.stream_context():
+            inv = [nt.begin(part(dots, k), True, None, slot=k) for k in range(3)]
+            fwd = []
+            for k in range(3):
+                nt.finish(inv[k], out=part(tmp, k))
+                fwd.append(nt.begin(part(tmp, k), False, self.g, slot=k))
+            for k in range(3):
+                nt.finish(fwd[k], out=part(dots, k))
+            nt.ops.pointwise_h(dots[:L], dots[L:2 * L], dots[2 * L:], tmp[:L], nt.log_n, self.g)
+            h = nt.finish(nt.begin(tmp[:L], True, self.g, slot=0), out=tmp[L:2 * L])
         ok, _, _ = self.sharded._reduce(verdict, first, False)
         return h, ok

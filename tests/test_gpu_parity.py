@@ -854,6 +854,26 @@ def test_bench_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
+def test_bench_force_dist_rccl_one_rank():
+    """bench.py --force-dist: the multi-rank code path with the nccl (= RCCL) backend on the one GPU of this box.  The
+    all-to-alls are really issued (DistributedNTT(force_collective=True)), asynchronously on RCCL's stream, and the
+    pipeline's local steps are ordered against them through Work.wait(): the transform must match the oracle and the
+    h(x) pipeline must accept the satisfying witness and reject the corrupted one."""
+    _need_gpu()
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29619", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "3",
+           "--copies", "4", "--no-cpu", "--no-ntt", "--dist-logn", "18"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["dist_ntt"]["parity_vs_oracle"] is True
+    assert d["dist_qap_h"]["accepts_valid_rejects_corrupt"] is True and d["dist_qap_h"]["exchange_overlapped"] is True
+
+
+@pytest.mark.gpu
 def test_sharded_layer_two_ranks_on_one_device():
     """ShardedR1CS and the four-step DistributedNTT with the HIP local kernels, world size 2, both ranks on
     cuda:0 over gloo (tests/dist_worker_gpu.py)."""
