@@ -10,5 +10,5 @@ from .circuit import (Add, ArithCircuit, ConstGate, Equal, InputWire, Intermedia
 from .qap import (GenQAP, NaiveQAP, QAP, QapSet, arithCircuitToGenQAP, arithCircuitToQAP, arithCircuitToQAPFFT,
                   createPolynomials, createPolynomialsFFT,
                   gateToQAP, generateAssignment, generateAssignmentGate, initialQapSet, lookupAtWire,
-                  qapSetToMap, verificationWitness, verificationWitnessZk, verifyAssignment)
+                  qapSetToMap, verificationWitness, verificationWitnessZk, verifyAssignment, verifyAssignments)
 from . import expr, json_io, parallel, synth  # noqa: E402  (host-side mirrors and utilities)

@@ -69,6 +69,7 @@ SYMBOLS = {
     "acx_r1cs_destroy": (None, [_P]),
     "acx_r1cs_dims": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U32), C.POINTER(_U64 * 3)]),
     "acx_r1cs_format": (_I, [_P, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U64)]),
+    "acx_r1cs_verify_many": (_I, [_P, _U64, _P, _P, _P, _P]),
     "acx_r1cs_export": (_I, [_P, _I, _P, _P, _P]),
     "acx_r1cs_verify": (_I, [_P, _P, C.POINTER(_I), C.POINTER(_U64), C.POINTER(_U64)]),
     "acx_r1cs_eval": (_I, [_P, _P, _P, _U64, _P, _P]),

@@ -1497,6 +1497,62 @@ int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad
     return ACX_OK;
 }
 
+// `all (verifyAssignment qap) assignments` (test/Test/Circuit/Arithmetic.hs:209) in one call: every witness of a chunk
+// crosses PCIe in ONE copy, is converted by one kernel, and the chunk is verified by ONE batched launch (blockIdx.y =
+// witness; the constraint stream of the system is shared by all of them and stays in L2 / Infinity Cache).
+int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad, uint64_t* first_bad) {
+    if (!r || !ok || (count && !witnesses)) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (count == 0) return ACX_OK;
+    return guarded([&]() -> int {
+        acx_ctx* c = r->ctx;
+        LaneGuard lane(c);
+        HIP_TRY(hipSetDevice(c->device));
+        size_t budget = (size_t)256 << 20;                                 // device bytes of witnesses per chunk
+        if (const char* e = std::getenv("ACX_VERIFY_MANY_CHUNK_BYTES")) budget = (size_t)std::max(1ll, std::atoll(e));
+        const uint64_t wbytes = r->m * 32;
+        const uint64_t chunk_max = std::max<uint64_t>(1, std::min<uint64_t>({count, budget / wbytes, (uint64_t)65535}));
+        std::vector<SellSystem> desc(chunk_max);
+        std::vector<unsigned long long> res(2 * chunk_max);
+        const size_t off_res = align256(chunk_max * wbytes), off_desc = align256(off_res + chunk_max * 16);
+        uint8_t* base = nullptr;
+        ACX_TRY(lane_reserve(c, off_desc + chunk_max * sizeof(SellSystem), &base));
+        uint4* d_w = (uint4*)base;
+        unsigned long long* d_res = (unsigned long long*)(base + off_res);
+        SellSystem* d_desc = (SellSystem*)(base + off_desc);
+        for (uint64_t done = 0; done < count; done += chunk_max) {
+            const uint64_t k = std::min(chunk_max, count - done);
+            ACX_TRY(upload_elements(c, witnesses + done * r->m, k * r->m, d_w));       // + canonicity of every element
+            for (uint64_t i = 0; i < k; ++i) {
+                res[2 * i] = 0; res[2 * i + 1] = ~0ull;
+                desc[i] = sell_system(r, d_w + 2 * i * r->m, ResidualOut{d_res + 2 * i, nullptr, nullptr, 0, 0});
+            }
+            HIP_TRY(hipMemcpyAsync(d_res, res.data(), k * 16, hipMemcpyHostToDevice, cur_stream(c)));
+            HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), k * sizeof(SellSystem), hipMemcpyHostToDevice, cur_stream(c)));
+            if (r->n_slices) {
+                const dim3 grid(sell_grid_x(r->n_slices), (unsigned)k, 1);
+                if (sell_spec(r)) {
+                    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 1>), grid, dim3(kBlock), 0, cur_stream(c),
+                                                         (const SellSystem*)d_desc, SellSystem{}));
+                } else {
+                    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 0>), grid, dim3(kBlock), 0, cur_stream(c),
+                                                         (const SellSystem*)d_desc, SellSystem{}));
+                }
+                HIP_TRY(hipGetLastError());
+            }
+            if (r->n_long)
+                for (uint64_t i = 0; i < k; ++i) ACX_TRY(launch_long_rows(r, desc[i].w, desc[i].out));
+            HIP_TRY(hipMemcpyAsync(res.data(), d_res, k * 16, hipMemcpyDeviceToHost, cur_stream(c)));
+            HIP_TRY(hipStreamSynchronize(cur_stream(c)));
+            for (uint64_t i = 0; i < k; ++i) {
+                ok[done + i] = res[2 * i] == 0;
+                if (n_bad) n_bad[done + i] = res[2 * i];
+                if (first_bad) first_bad[done + i] = res[2 * i + 1];
+            }
+        }
+        return ACX_OK;
+    });
+}
+
 int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs, acx_fr* witness,
                   uint8_t* assigned) {
     if (!r || (n_inputs && !inputs)) return fail(ACX_ERR_INVALID_ARG, "null argument");

@@ -170,6 +170,20 @@ class R1CS:
         check(self.ctx.lib.acx_r1cs_verify(self._h, _ptr(w), C.byref(ok), C.byref(nbad), C.byref(first)))
         return bool(ok.value), nbad.value, first.value
 
+    def verify_many(self, witnesses: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """`all (verifyAssignment qap) assignments` in one call: witnesses (count, m, 4) canonical ->
+        (ok[count] bool, n_bad[count], first_bad[count])."""
+        w = np.ascontiguousarray(witnesses, dtype=np.uint64)
+        if w.ndim != 3 or w.shape[1:] != (self.m, 4):
+            raise ValueError(f"witnesses must have shape (count, {self.m}, 4)")
+        count = w.shape[0]
+        ok = np.zeros(count, dtype=np.uint8)
+        nbad = np.zeros(count, dtype=np.uint64)
+        first = np.zeros(count, dtype=np.uint64)
+        check(self.ctx.lib.acx_r1cs_verify_many(self._h, count, w.ctypes.data if count else None, ok.ctypes.data,
+                                                nbad.ctypes.data, first.ctypes.data))
+        return ok.astype(bool), nbad, first
+
     def eval_witness(self, inputs: np.ndarray, present: Optional[np.ndarray] = None,
                      download: bool = True) -> Tuple[Optional[np.ndarray], np.ndarray]:
         """generateAssignment on the GPU (level-parallel); the witness stays device resident."""

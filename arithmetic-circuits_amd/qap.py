@@ -173,6 +173,16 @@ def verifyAssignment(qap: QAP, assignment: QapSet) -> bool:
     return ok
 
 
+def verifyAssignments(qap: QAP, assignments: Sequence[QapSet]) -> List[bool]:
+    """`map (verifyAssignment qap) assignments` -- the shape of test/Test/Circuit/Arithmetic.hs:209 (one QAP, many
+    assignments) -- in one call across the C ABI (acx_r1cs_verify_many: one PCIe copy and one batched launch)."""
+    if not assignments:
+        return []
+    w = np.stack([qap.gen.witness_vector(a) for a in assignments])
+    ok, _, _ = qap.gen.r1cs.verify_many(w)
+    return [bool(x) for x in ok]
+
+
 def verificationWitnessZk(delta1: int, delta2: int, delta3: int, qap: QAP, assignment: QapSet) -> Optional[List[int]]:
     p = qap.gen.ctx.p
     d = [delta1 % p, delta2 % p, delta3 % p]

@@ -187,6 +187,13 @@ int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* c
  * either may be NULL.  witness[m] canonical (absent wires = 0, `combineWithDefaults`
  * src/QAP.hs:163-181,314). */
 int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad);
+/* `all (verifyAssignment qap . generateAssignment program) inputs` (test/Test/Circuit/Arithmetic.hs:200-209: build the
+ * QAP once, verify many assignments) in ONE call: witnesses = count x m canonical elements, witness k at
+ * witnesses[k*m].  ok[k] (and n_bad[k], first_bad[k] when given) as acx_r1cs_verify would report them.  The witnesses
+ * cross PCIe in one copy per chunk (256 MiB of device memory per chunk) and a chunk is verified by one batched
+ * launch; any non-canonical element fails the whole call with ACX_ERR_NONCANONICAL. */
+int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad,
+                         uint64_t* first_bad);
 /* `generateAssignment` on the GPU: the gates are evaluated level by level (a
  * level = gates whose inputs are all produced by earlier levels), one launch per level; Mul gates
  * reuse their own constraint rows.  Available for systems built by acx_circuit_to_r1cs from a

@@ -726,9 +726,11 @@ def test_prop_compiledQAPValid_gpu(request, acx, seed):
     n_rows = sum(len(r) for r in roots)
     qap_fft = acx.arithCircuitToQAPFFT(ctx, roots, program)
     qap_naive = acx.arithCircuitToQAP(ctx, roots, program) if n_rows <= 4096 else None
+    seen = []
     for _ in range(5):
         inputs = H.arb_input_vector(rnd, p, nv)
         a = acx.generateAssignment(program, inputs)
+        seen.append(a)
         assert acx.verifyAssignment(qap_fft, a)
         if qap_naive is not None:
             assert acx.verifyAssignment(qap_naive, a)
@@ -743,6 +745,8 @@ def test_prop_compiledQAPValid_gpu(request, acx, seed):
         if n_rows <= 64:
             oqap = R.arith_circuit_to_qap_fft(R.BN254.root_of_unity, R.fresh_roots(ogates, 0), ogates, p)
             assert acx.verificationWitness(qap_fft, a) == R.verification_witness(oqap, ra, p)
+    # `all (verifyAssignment qap . generateAssignment program) inputs` as ONE call (acx_r1cs_verify_many)
+    assert acx.verifyAssignments(qap_fft, seen) == [True] * 5 and acx.verifyAssignments(qap_fft, []) == []
 
 
 @pytest.mark.parametrize("field,log_n", [("bn254", 25), ("bls12_381", 26)])
@@ -1116,3 +1120,49 @@ def test_small_coefficient_mulgraph_h_and_columns(request, acx, field):
     assert np.array_equal(r0.residuals(w2), got)
     r0.close()
     ctx0.close()
+
+
+# ------------------------------------------------------------------ build once, verify many (host buffers)
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+def test_verify_many_matches_single_calls_and_oracle(request, acx, field):
+    """acx_r1cs_verify_many = `all (verifyAssignment qap . generateAssignment program) inputs`
+    (test/Test/Circuit/Arithmetic.hs:200-209): 60 assignments of one random circuit (Mul / Equal / Split rows, so the
+    CSR long-row kernel runs per witness too), a third of them corrupted in one wire -- verdict, violated-row count
+    and first violated row per witness equal to single acx_r1cs_verify calls and to the oracle's residuals; forced
+    chunking (3 witnesses per chunk) gives the same answers; a non-canonical element anywhere fails the call; count 0."""
+    ctx, orc = _ctx(request, field), _orc(request, field)
+    p = ctx.p
+    rnd = random.Random(4711)
+    n_in = 4
+    gates = H.arb_arith_circuit(rnd, p, n_in, 40, dist=(50, 10, 2), split_bits=256)
+    circ = H.to_acx_circuit(acx, gates).marshal(field)
+    r = circ.to_r1cs(ctx)
+    mats = circ.rows()
+    assert r.format()[2] > 0                               # Split rows: the CSR long-row kernel runs per witness
+    ws = []
+    for k in range(60):
+        w, _ = circ.eval(acx.ints_to_fr([rnd.randrange(p) for _ in range(n_in)]))
+        if k % 3 == 1:
+            w = w.copy()
+            w[rnd.randrange(1, r.m), 0] ^= np.uint64(1 + rnd.randrange(7))
+        ws.append(w)
+    W = np.stack(ws)
+    ok, nbad, first = r.verify_many(W)
+    assert ok.sum() >= 40 and (~ok).sum() >= 1
+    for k in range(60):
+        assert (bool(ok[k]), int(nbad[k]), int(first[k])) == r.verify(ws[k])
+        _, nb, fb = orc.r1cs_residuals(r.n, r.m, *mats, ws[k])
+        assert (int(nbad[k]), int(first[k])) == (nb, fb)
+    os.environ["ACX_VERIFY_MANY_CHUNK_BYTES"] = str(3 * r.m * 32)
+    try:
+        ok2, nbad2, first2 = r.verify_many(W)
+    finally:
+        del os.environ["ACX_VERIFY_MANY_CHUNK_BYTES"]
+    assert np.array_equal(ok, ok2) and np.array_equal(nbad, nbad2) and np.array_equal(first, first2)
+    bad = W.copy()
+    bad[37, 5, :] = np.uint64(0xFFFFFFFFFFFFFFFF)          # >= p
+    with pytest.raises(acx.AcxError) as e:
+        r.verify_many(bad)
+    assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
+    ok0, _, _ = r.verify_many(np.zeros((0, r.m, 4), dtype=np.uint64))
+    assert ok0.shape == (0,)
