@@ -760,8 +760,21 @@ SellSystem sell_system(const acx_r1cs* r, const uint4* d_w, const ResidualOut& o
     return S;
 }
 
-// the launch can use the instance specialised for compiled programs (small A and B, unit C)
-inline bool sell_spec(const acx_r1cs* r) { return (r->small & 3u) == 3u && r->unit_c; }
+// which k_r1cs_sell instance a system can run on: 0 full-width only, 1 compiled-program shape (small A and B, unit C),
+// 2 mixed (per-matrix run-time flags)
+inline int sell_spec(const acx_r1cs* r) {
+    if (r->small == 0) return 0;
+    return ((r->small & 3u) == 3u && r->unit_c) ? 1 : 2;
+}
+inline int sell_spec_join(int a, int b) { return a == b ? a : 2; }
+
+inline void launch_sell(acx_ctx* c, int spec, dim3 grid, const SellSystem* systems, const SellSystem& one) {
+    DISPATCH_FIELD(c, {
+        if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell<F, 0>), grid, dim3(kBlock), 0, cur_stream(c), systems, one);
+        else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell<F, 1>), grid, dim3(kBlock), 0, cur_stream(c), systems, one);
+        else hipLaunchKernelGGL((k_r1cs_sell<F, 2>), grid, dim3(kBlock), 0, cur_stream(c), systems, one);
+    });
+}
 
 inline unsigned sell_grid_x(uint32_t n_slices) {
     const uint32_t tiles = (n_slices + 3) / 4;
@@ -792,13 +805,7 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
     const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset};
     const SellSystem S = sell_system(r, d_w, out);
     const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
-    if (sell_spec(r)) {
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 1>), grid, dim3(kBlock), 0, cur_stream(c),
-                                             (const SellSystem*)nullptr, S));
-    } else {
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 0>), grid, dim3(kBlock), 0, cur_stream(c),
-                                             (const SellSystem*)nullptr, S));
-    }
+    launch_sell(c, sell_spec(r), grid, nullptr, S);
     HIP_TRY(hipGetLastError());
     return launch_long_rows(r, d_w, out);
 }
@@ -1530,13 +1537,7 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
             HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), k * sizeof(SellSystem), hipMemcpyHostToDevice, cur_stream(c)));
             if (r->n_slices) {
                 const dim3 grid(sell_grid_x(r->n_slices), (unsigned)k, 1);
-                if (sell_spec(r)) {
-                    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 1>), grid, dim3(kBlock), 0, cur_stream(c),
-                                                         (const SellSystem*)d_desc, SellSystem{}));
-                } else {
-                    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 0>), grid, dim3(kBlock), 0, cur_stream(c),
-                                                         (const SellSystem*)d_desc, SellSystem{}));
-                }
+                launch_sell(c, sell_spec(r), grid, d_desc, SellSystem{});
                 HIP_TRY(hipGetLastError());
             }
             if (r->n_long)
@@ -2063,15 +2064,9 @@ int acx_batch_verify_dev(acx_batch* b) {
     HIP_TRY(hipSetDevice(c->device));
     if (b->max_slices) {
         const dim3 grid(sell_grid_x(b->max_slices), (unsigned)b->systems.size(), 1);
-        bool spec = true;
-        for (const acx_r1cs* r : b->systems) spec = spec && sell_spec(r);
-        if (spec) {
-            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 1>), grid, dim3(kBlock), 0, cur_stream(c),
-                                                 (const SellSystem*)b->d_systems, SellSystem{}));
-        } else {
-            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_r1cs_sell<F, 0>), grid, dim3(kBlock), 0, cur_stream(c),
-                                                 (const SellSystem*)b->d_systems, SellSystem{}));
-        }
+        int spec = sell_spec(b->systems[0]);
+        for (const acx_r1cs* r : b->systems) spec = sell_spec_join(spec, sell_spec(r));
+        launch_sell(c, spec, grid, b->d_systems, SellSystem{});
         HIP_TRY(hipGetLastError());
     }
     for (size_t i = 0; i < b->systems.size(); ++i)

@@ -324,8 +324,10 @@ struct SellSystem {
 // so XCD x gets the contiguous tile range [x*T/8, (x+1)*T/8): the rows in flight on an XCD, and
 // the witness window they gather from, stay inside its private 4 MiB L2.  gridDim.x = tiles
 // rounded up to a multiple of 8.
+// SPEC = 0: no matrix of the launch is in the small-coefficient form (the full-width path alone).
 // SPEC = 1: every system of the launch has small-coefficient A and B and a unit C (the shape of a compiled program);
-// the instance then carries none of the deferred-reduction path's registers.
+//           the instance then carries none of the deferred-reduction path's registers (58 VGPRs, 8 waves per SIMD).
+// SPEC = 2: anything else; the form of each matrix is a run-time flag of its system.
 template <class F, int SPEC = 0>
 __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
     const SellSystem& S = systems != nullptr ? systems[blockIdx.y] : one;   // batched : single
@@ -343,12 +345,14 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
     u32 row = kNoRow;
     if (slice < S.n_slices) {
         row = gload(S.perm + slice * kSlice + lane);
-        a = (SPEC == 1 || (S.small & 1u)) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
+        constexpr bool kMixed = SPEC == 2;            // SPEC 0 carries no small-coefficient code at all (it costs the
+                                                      // full-width path ~2 % when merely present in the kernel)
+        a = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
 #pragma unroll
         for (int i = 0; i < kLimbs; ++i) park[i][threadIdx.x] = a.l[i];
-        b = (SPEC == 1 || (S.small & 2u)) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
+        b = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
         c = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
-            : (S.small & 4u) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
+            : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
 #pragma unroll
         for (int i = 0; i < kLimbs; ++i) a.l[i] = park[i][threadIdx.x];
     }
