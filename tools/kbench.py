@@ -107,6 +107,27 @@ def bench_h(ctx, log_n):
     print(f"qap_h n=2^{log_n}: {dt * 1e3:9.2f} ms per call (host in/out, includes H2D of w and D2H of h)")
 
 
+def bench_cols(ctx, stream, log_n, wires=64):
+    """createPolynomialsFFT throughput (src/QAP.hs:512-525): per-wire interpolation of `wires` columns of A at a time --
+    device-resident (acx_qap_columns_dev: scatter, batched iNTT, stripped lengths) and through host buffers
+    (acx_qap_columns: the same plus the D2H of every coefficient, double-buffered against the next batch's kernels)."""
+    n = 1 << log_n
+    s = synth.mulgraph(n)
+    r = s.circuit.to_r1cs(ctx)
+    out = torch.empty((wires * n, 4), dtype=torch.int64, device="cuda")
+    lens = torch.zeros(wires, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    us = time_stream(stream, lambda: r.qap_columns_dev(0, 1, wires, out.data_ptr(), lens.data_ptr()), 5)
+    print(f"qap_columns_dev N=2^{log_n}, {wires} wires per call: {us:9.1f} us = {us / wires:7.1f} us per column, {wires / us * 1e6:.0f} columns/s")
+    total = 4 * wires
+    r.qap_columns(0, 1, wires)
+    t0 = time.perf_counter()
+    r.qap_columns(0, 1, total)
+    dt = time.perf_counter() - t0
+    print(f"qap_columns (host buffers) N=2^{log_n}, {total} wires: {dt * 1e3:9.1f} ms = {dt / total * 1e6:7.1f} us per column, "
+          f"{total * n * 32 / dt / 1e9:.1f} GB/s of coefficients to the host")
+
+
 N_IN, WINDOW, COEFF = 1024, 4096, "random"
 
 
@@ -131,6 +152,8 @@ def main():
             bench_ntt(ctx, stream, ln, a.reps)
         if a.what == "nttbatch":
             bench_ntt(ctx, stream, ln, a.reps, batch=64 if ln <= 20 else 8)
+        if a.what == "cols":
+            bench_cols(ctx, stream, ln)
         if a.what == "h":
             bench_h(ctx, ln)
 
