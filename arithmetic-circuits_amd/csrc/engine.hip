@@ -279,6 +279,28 @@ int upload_elements(acx_ctx* c, const acx_fr* host, uint64_t count, uint4* d_out
     return ACX_OK;
 }
 
+// The same without the host round trip, for entry points that end with a result fetch anyway: the call's slot
+// {n_bad, first_bad, canonicity flag} is initialised by ONE 32-byte copy (begin_call), the conversion raises the flag on the
+// device, and end_call fetches all three words with ONE copy before the single stream synchronisation -- a small
+// system's verify is five enqueues and one wait.
+struct CallSlot { unsigned long long n_bad, first_bad; uint32_t noncanonical, pad[3]; };
+static_assert(sizeof(CallSlot) == 32, "slot layout");
+
+int begin_call(acx_ctx* c) {
+    static const CallSlot init{0ull, ~0ull, 0u, {0u, 0u, 0u}};
+    HIP_TRY(hipMemcpyAsync(cur_result(c), &init, sizeof(init), hipMemcpyHostToDevice, cur_stream(c)));
+    return ACX_OK;
+}
+int upload_elements_async(acx_ctx* c, const acx_fr* host, uint64_t count, uint4* d_out) {   // after begin_call
+    if (count == 0) return ACX_OK;
+    HIP_TRY(hipMemcpyAsync(d_out, host, count * 32, hipMemcpyHostToDevice, cur_stream(c)));
+    return launch_convert(c, true, d_out, d_out, count, cur_err(c));
+}
+inline int end_call_fetch(acx_ctx* c, CallSlot* host) {      // the caller synchronises the stream afterwards
+    HIP_TRY(hipMemcpyAsync(host, cur_result(c), sizeof(CallSlot), hipMemcpyDeviceToHost, cur_stream(c)));
+    return ACX_OK;
+}
+
 int download_elements(acx_ctx* c, const uint4* d_in, uint64_t count, acx_fr* host, uint4* d_scratch) {
     if (count == 0) return ACX_OK;
     ACX_TRY(launch_convert(c, false, d_in, d_scratch, count, nullptr));
@@ -481,10 +503,13 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         if (cfg.n_digits && sum == log_n) {
             P = cfg.n_digits;
             for (int i = 0; i < P; ++i) lg[i] = cfg.digits[i];
-        } else if (log_n <= 12 && (log_n % 2 == 0 || batch_pow2 >= 2)) {
-            P = 1; lg[0] = log_n;
+        } else if (log_n <= 12 && (log_n % 2 == 0 || batch_pow2 >= 2) && (log_n <= 10 || batch >= 128)) {
+            P = 1; lg[0] = log_n;                         // one workgroup per transform: right once a batch fills the chip
         } else if (log_n <= 12) {
-            P = 2; lg[0] = log_n - 5; lg[1] = 5;          // odd digit, single transform: the 5-bit pass brings the column pairs
+            // few transforms of 2^11 / 2^12 points: a single 1024-thread workgroup per transform leaves the chip idle
+            // (2^12: 55 us alone, 19 us per transform in a batch of 3); two passes spread the work (25 us, 8.8 us).
+            // Also the odd single transform, whose 5-bit pass brings the column pairs.
+            P = 2; lg[0] = log_n - 5; lg[1] = 5;
         } else if (log_n <= 17) {
             P = 2; lg[0] = log_n - 8; lg[1] = 8;          // measured best (tools/ntt_sweep.sh, profiles/r02_ntt_plans.txt)
         } else if (log_n <= 20) {
@@ -1157,10 +1182,12 @@ int acx_ctx_create(int field, int device_id, acx_ctx** out) {
     c->ntt = ntt_cfg_from_env();
     if (const char* e = std::getenv("ACX_R1CS_SMALL")) c->small_coeff = std::atoi(e) != 0;   // development A/B switch
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void**)&c->d_result, 16) == hipSuccess && hipMalloc((void**)&c->d_err, 4) == hipSuccess;
+              hipMalloc((void**)&c->d_result, 32) == hipSuccess;      // {n_bad, first_bad, canonicity flag, pad}: one copy in, one out
+    if (ok) c->d_err = (uint32_t*)(c->d_result + 2);
     for (auto& ln : c->lanes)
         ok = ok && hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess &&
-             hipMalloc((void**)&ln.d_result, 16) == hipSuccess && hipMalloc((void**)&ln.d_err, 4) == hipSuccess;
+             hipMalloc((void**)&ln.d_result, 32) == hipSuccess;
+    if (ok) for (auto& ln : c->lanes) ln.d_err = (uint32_t*)(ln.d_result + 2);
     if (!ok) {
         acx_ctx_destroy(c);
         return fail(ACX_ERR_HIP, "context resource creation failed");
@@ -1179,12 +1206,10 @@ void acx_ctx_destroy(acx_ctx* c) {
     for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
     if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
     for (auto& e : c->cosets) { if (e.lo) (void)hipFree(e.lo); if (e.hi) (void)hipFree(e.hi); }
-    if (c->d_result) (void)hipFree(c->d_result);
-    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_result) (void)hipFree(c->d_result);                   // d_err lives inside it
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto& ln : c->lanes) {
         if (ln.d_result) (void)hipFree(ln.d_result);
-        if (ln.d_err) (void)hipFree(ln.d_err);
         if (ln.arena) (void)hipFree(ln.arena);
         if (ln.ntt_scratch) (void)hipFree(ln.ntt_scratch);
         for (auto& e : ln.ev) if (e) (void)hipEventDestroy(e);
@@ -1478,15 +1503,15 @@ int acx_r1cs_export(const acx_r1cs* r, int matrix, uint32_t* rowptr, uint32_t* c
 static int verify_common(acx_r1cs* r, const acx_fr* witness, uint4* d_w, uint64_t* n_bad, uint64_t* first_bad, uint4* d_res,
                          uint4* d_dots, uint64_t dots_stride) {
     acx_ctx* c = r->ctx;
-    ACX_TRY(upload_elements(c, witness, r->m, d_w));
-    const unsigned long long init[2] = {0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(cur_result(c), init, 16, hipMemcpyHostToDevice, cur_stream(c)));
+    ACX_TRY(begin_call(c));
+    ACX_TRY(upload_elements_async(c, witness, r->m, d_w));
     ACX_TRY(launch_residual(r, d_w, 0, cur_result(c), d_res, d_dots, dots_stride));
-    unsigned long long res[2];
-    HIP_TRY(hipMemcpyAsync(res, cur_result(c), 16, hipMemcpyDeviceToHost, cur_stream(c)));
+    CallSlot slot;
+    ACX_TRY(end_call_fetch(c, &slot));
     HIP_TRY(hipStreamSynchronize(cur_stream(c)));
-    if (n_bad) *n_bad = res[0];
-    if (first_bad) *first_bad = res[1];
+    if (slot.noncanonical) return fail(ACX_ERR_NONCANONICAL, "element >= p");
+    if (n_bad) *n_bad = slot.n_bad;
+    if (first_bad) *first_bad = slot.first_bad;
     return ACX_OK;
 }
 
@@ -1528,7 +1553,8 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
         SellSystem* d_desc = (SellSystem*)(base + off_desc);
         for (uint64_t done = 0; done < count; done += chunk_max) {
             const uint64_t k = std::min(chunk_max, count - done);
-            ACX_TRY(upload_elements(c, witnesses + done * r->m, k * r->m, d_w));       // + canonicity of every element
+            ACX_TRY(begin_call(c));
+            ACX_TRY(upload_elements_async(c, witnesses + done * r->m, k * r->m, d_w));  // canonicity flag fetched below
             for (uint64_t i = 0; i < k; ++i) {
                 res[2 * i] = 0; res[2 * i + 1] = ~0ull;
                 desc[i] = sell_system(r, d_w + 2 * i * r->m, ResidualOut{d_res + 2 * i, nullptr, nullptr, 0, 0});
@@ -1542,8 +1568,11 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
             }
             if (r->n_long)
                 for (uint64_t i = 0; i < k; ++i) ACX_TRY(launch_long_rows(r, desc[i].w, desc[i].out));
+            CallSlot slot;
             HIP_TRY(hipMemcpyAsync(res.data(), d_res, k * 16, hipMemcpyDeviceToHost, cur_stream(c)));
+            ACX_TRY(end_call_fetch(c, &slot));
             HIP_TRY(hipStreamSynchronize(cur_stream(c)));
+            if (slot.noncanonical) return fail(ACX_ERR_NONCANONICAL, "element >= p");
             for (uint64_t i = 0; i < k; ++i) {
                 ok[done + i] = res[2 * i] == 0;
                 if (n_bad) n_bad[done + i] = res[2 * i];
@@ -1705,14 +1734,14 @@ int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* o
     ACX_TRY(lane_reserve(c, wb + hb + 5 * N * 32, &base));
     uint4* d_wit = (uint4*)base;
     uint4* d_h = (uint4*)(base + wb);
-    ACX_TRY(upload_elements(c, witness, r->m, d_wit));
-    const unsigned long long init[2] = {0ull, ~0ull};
-    HIP_TRY(hipMemcpyAsync(cur_result(c), init, 16, hipMemcpyHostToDevice, cur_stream(c)));
+    ACX_TRY(begin_call(c));
+    ACX_TRY(upload_elements_async(c, witness, r->m, d_wit));
     ACX_TRY(qap_h_dev_locked(r, d_wit, delta ? dl : nullptr, d_h, cur_result(c), (uint4*)(base + wb + hb)));
-    unsigned long long res[2];
-    HIP_TRY(hipMemcpyAsync(res, cur_result(c), 16, hipMemcpyDeviceToHost, cur_stream(c)));
-    ACX_TRY(download_elements(c, d_h, N + 1, out_h, d_h + 2 * (N + 1)));
-    *ok = res[0] == 0;
+    CallSlot slot;
+    ACX_TRY(end_call_fetch(c, &slot));
+    ACX_TRY(download_elements(c, d_h, N + 1, out_h, d_h + 2 * (N + 1)));                 // synchronises the stream
+    if (slot.noncanonical) return fail(ACX_ERR_NONCANONICAL, "element >= p");
+    *ok = slot.n_bad == 0;
     uint64_t len = N + 1;
     static const uint8_t zero32[32] = {0};
     while (len > 0 && std::memcmp(out_h[len - 1].b, zero32, 32) == 0) --len;
