@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <atomic>
 #include <map>
 #include <memory>
@@ -31,6 +32,18 @@ static int fail(int code, const std::string& msg) {
 }
 
 // Nothing may propagate through the C ABI: host allocations sized by caller data can throw.
+// ACX_TRACE_LOAD=1: wall-clock of the phases of acx_r1cs_load / acx_circuit_to_r1cs on stderr (development aid)
+struct PhaseTimer {
+    bool on = std::getenv("ACX_TRACE_LOAD") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[acx load] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 template <class Fn>
 static int guarded(Fn&& fn) {
     try {
@@ -844,22 +857,28 @@ int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
     const uint32_t n_slices = (uint32_t)((n + kSlice - 1) / kSlice);
     r->n_slices = n_slices;
     if (n == 0) return ACX_OK;
+    PhaseTimer pt;
     std::vector<uint32_t> key(n), perm((size_t)n_slices * kSlice, kNoRow), longs;
+    // Row classes: (lenA, lenB, lenC) with every length <= kSellMaxLen, or "long".  Few classes, so the stable sort of a
+    // window is a counting sort (a comparison sort of 2^20 rows cost 32 ms of a 110 ms load).
+    constexpr uint32_t kLenRadix = kSellMaxLen + 1, kLongClass = kLenRadix * kLenRadix * kLenRadix;
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t l[3];
         bool is_long = false;
         for (int k = 0; k < 3; ++k) { l[k] = rowptr[k][i + 1] - rowptr[k][i]; is_long = is_long || l[k] > (uint32_t)kSellMaxLen; }
-        key[i] = is_long ? 0xffffffffu : ((l[0] << 16) | (l[1] << 8) | l[2]);
+        key[i] = is_long ? kLongClass : (l[0] * kLenRadix + l[1]) * kLenRadix + l[2];
         if (is_long) longs.push_back((uint32_t)i);
     }
-    std::vector<uint32_t> idx;
+    std::vector<uint32_t> start(kLongClass + 2);
     for (uint64_t ws = 0; ws < n; ws += kSellWindow) {
         const uint64_t we = std::min<uint64_t>(ws + kSellWindow, n);
-        idx.resize(we - ws);
-        for (uint64_t i = ws; i < we; ++i) idx[i - ws] = (uint32_t)i;
-        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
-        for (uint64_t i = ws; i < we; ++i) perm[i] = key[idx[i - ws]] == 0xffffffffu ? kNoRow : idx[i - ws];
+        std::fill(start.begin(), start.end(), 0u);
+        for (uint64_t i = ws; i < we; ++i) ++start[key[i] + 1];
+        for (uint32_t k = 0; k <= kLongClass; ++k) start[k + 1] += start[k];
+        for (uint64_t i = ws; i < we; ++i)                       // ascending class, original order inside a class
+            perm[ws + start[key[i]]++] = key[i] == kLongClass ? kNoRow : (uint32_t)i;
     }
+    pt.mark("  sell: keys + window sorts");
     HIP_TRY(hipMalloc((void**)&r->perm, perm.size() * 4));
     HIP_TRY(hipMemcpyAsync(r->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
     r->n_long = (uint32_t)longs.size();
@@ -879,6 +898,7 @@ int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
             ofs[s + 1] = ofs[s] + mx;
         }
         const uint64_t slots = ofs[n_slices];
+        pt.mark("  sell: slice offsets");
         HIP_TRY(hipMalloc((void**)&r->sell_ofs[k], ofs.size() * 4));
         HIP_TRY(hipMalloc((void**)&r->sell_tail[k], std::max<uint64_t>(slots, 1) * kSlice * 8));
         const bool small = (r->small >> k) & 1u;
@@ -902,6 +922,7 @@ int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
         }
     }
     HIP_TRY(hipStreamSynchronize(cur_stream(c)));
+    pt.mark("  sell: device build");
     return ACX_OK;
 }
 
@@ -1041,6 +1062,7 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
     if (!r) return fail(ACX_ERR_OOM, "host allocation failed");
     r->ctx = ctx; r->n = n; r->m = m; r->log_n = log_n;
     int rc = ACX_OK;
+    PhaseTimer pt;
     try {                                              // host vectors are sized by caller data
         std::vector<uint32_t> rowptrs[3];
         for (int k = 0; k < 3 && rc == ACX_OK; ++k) {
@@ -1048,6 +1070,7 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
             std::vector<uint32_t> col;
             std::vector<acx_fr> val;
             rc = normalise_csr(ctx->hf, n, m, mats[k], rowptr, col, val);
+            pt.mark("normalise_csr");
             if (rc == ACX_OK && k == 2) {
                 static const uint8_t one32[32] = {1};
                 bool unit = true;
@@ -1066,9 +1089,12 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
                 }
                 if (small) r->small |= 1u << k;
             }
+            pt.mark("classify");
             if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, col, val.data(), true, r->M[k]);
+            pt.mark("upload_matrix");
         }
         if (rc == ACX_OK) rc = build_sell(r, rowptrs);
+        pt.mark("build_sell");
         if (rc == ACX_OK) {
             hipError_t e = hipMalloc((void**)&r->d_w, m * 32);
             if (e != hipSuccess) rc = fail(ACX_ERR_OOM, "witness buffer allocation failed");
@@ -1390,7 +1416,10 @@ static int circuit_to_r1cs_impl(acx_ctx* ctx, const acx_circuit* c, const acx_fr
         views[k] = acx_csr{src->rowptr.data(), src->col.data(), reinterpret_cast<const acx_fr*>(src->val.data())};
     }
     const acx_csr* mats[3] = {&views[0], &views[1], &views[2]};
+    PhaseTimer pt;
     ACX_TRY(r1cs_from_host(ctx, hc.n_rows(), hc.m(), mats, out));
+    pt.mark("r1cs_from_host total");
+    struct AtExit { PhaseTimer& p; ~AtExit() { p.mark("evaluation plan"); } } at_exit{pt};
     // device evaluation plan (generateAssignment on the GPU), when the circuit allows it
     HostCircuit::EvalPlan plan;
     if (hc.n_gates > 0 && hc.n_gates < 0xffffffffull && hc.build_plan(plan)) {
