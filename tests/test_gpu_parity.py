@@ -1166,3 +1166,40 @@ def test_verify_many_matches_single_calls_and_oracle(request, acx, field):
     assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
     ok0, _, _ = r.verify_many(np.zeros((0, r.m, 4), dtype=np.uint64))
     assert ok0.shape == (0,)
+
+
+def test_device_memory_is_returned(request, acx):
+    """Handles own their device memory: loading, using and destroying systems, batches and contexts in a loop (all entry
+    points that allocate lazily: lanes' arenas, NTT scratch and tables, h(x) scratch, column views, both SELL forms) leaves
+    the device's free memory where it started."""
+    import gc
+    import importlib
+    import torch
+    synth = importlib.import_module("arithmetic-circuits_amd.synth")
+    _ctx(request, "bn254")                                   # the session's context exists before the measurement
+    torch.cuda.synchronize()
+
+    def cycle():
+        ctx = acx.Context("bn254", 0)
+        for coeff in ("random", "small"):
+            s = synth.mulgraph(1 << 12, n_in=64, window=256, coeff=coeff)
+            r = s.circuit.to_r1cs(ctx)
+            w = s.witness()
+            assert r.verify(w)[0] and r.qap_h(w)[1]
+            r.qap_columns(0, 0, 4)
+            r.verify_many(np.stack([w, w]))
+            r.eval_witness(s.inputs)
+            x = synth.random_fr(1 << 14, 3, 1)
+            ctx.ntt(x, 14, inverse=True, shift=5)
+            r.close()
+        ctx.close()
+        gc.collect()
+
+    cycle()                                                  # first cycle: one-time runtime allocations (code objects, ...)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), (free0, free1)
