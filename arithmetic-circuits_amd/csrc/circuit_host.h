@@ -10,6 +10,10 @@
 //   qapSetToMap numbering     src/QAP.hs:605-620
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <new>
+#include <thread>
 #include <map>
 #include <string>
 #include <vector>
@@ -23,6 +27,25 @@ struct SparseRow {
     std::vector<uint32_t> col;
     std::vector<H256> val;  // Montgomery (host radix)
 };
+
+// Worker threads for the host-side loops over gates / scalars (row generation is the reference's
+// arithCircuitToGenQAP, src/QAP.hs:530-539).  ACX_HOST_THREADS overrides the count.
+inline unsigned host_threads(uint64_t items, uint64_t grain) {
+    unsigned t = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 64u, (unsigned)(items / grain + 1)});
+    if (const char* e = std::getenv("ACX_HOST_THREADS")) t = (unsigned)std::max(1, std::atoi(e));
+    return t;
+}
+// body(t, begin, end) over a partition of [0, n) into T contiguous ranges; std::bad_alloc is carried to the caller
+template <class Body>
+inline void parallel_ranges(uint64_t n, unsigned T, Body&& body) {
+    if (T <= 1) { body(0u, (uint64_t)0, n); return; }
+    std::atomic<bool> oom{false};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([&, t] { try { body(t, n * t / T, n * (t + 1) / T); } catch (const std::bad_alloc&) { oom = true; } });
+    for (auto& x : th) x.join();
+    if (oom) throw std::bad_alloc();
+}
 
 struct HostCsr {
     std::vector<uint32_t> rowptr{0};
@@ -96,11 +119,17 @@ public:
         if (n_w) wires.assign(gl->wires, gl->wires + n_w);
         if (gl->n_aff_wires) aff_wires.assign(gl->aff_wires, gl->aff_wires + gl->n_aff_wires);
         scalars.resize(gl->n_scalars);
-        for (uint64_t i = 0; i < gl->n_scalars; ++i) {
-            H256 c;
-            std::memcpy(c.l, gl->scalars[i].b, 32);
-            if (!hf.is_canonical(c)) { msg = "scalar >= p"; return ACX_ERR_NONCANONICAL; }
-            scalars[i] = hf.to_mont(c);
+        {
+            std::atomic<bool> noncanonical{false};
+            parallel_ranges(gl->n_scalars, host_threads(gl->n_scalars, 1 << 16), [&](unsigned, uint64_t b, uint64_t e) {
+                for (uint64_t i = b; i < e; ++i) {
+                    H256 c;
+                    std::memcpy(c.l, gl->scalars[i].b, 32);
+                    if (!hf.is_canonical(c)) { noncanonical = true; return; }
+                    scalars[i] = hf.to_mont(c);
+                }
+            });
+            if (noncanonical) { msg = "scalar >= p"; return ACX_ERR_NONCANONICAL; }
         }
         auto bump = [&](const acx_wire& w) -> bool {
             if (w.kind > ACX_WIRE_OUTPUT || w.index >= 0x7fffffffu) return false;
@@ -110,23 +139,28 @@ public:
         };
         for (const auto& w : wires) if (!bump(w)) { msg = "bad wire"; return ACX_ERR_BAD_CIRCUIT; }
         for (const auto& w : aff_wires) if (!bump(w)) { msg = "bad wire"; return ACX_ERR_BAD_CIRCUIT; }
-        for (uint64_t g = 0; g < n_gates; ++g) {
-            const uint64_t nw = wire_ofs[g + 1] - wire_ofs[g];
-            const bool has_tok = tok_ofs[2 * g + 2] > tok_ofs[2 * g];
-            if (kind[g] == ACX_GATE_MUL) {
-                if (nw != 1) { msg = "Mul gate needs exactly one wire"; return ACX_ERR_BAD_CIRCUIT; }
-                for (int side = 0; side < 2; ++side) {
-                    uint64_t pos = tok_ofs[2 * g + side];
-                    if (!check_tree(pos, tok_ofs[2 * g + side + 1], gl) || pos != tok_ofs[2 * g + side + 1]) {
-                        msg = "malformed affine token stream"; return ACX_ERR_BAD_CIRCUIT;
+        const unsigned T = host_threads(n_gates, 1 << 14);
+        std::vector<const char*> err(T, nullptr);            // first problem of every gate range; the lowest range reports
+        parallel_ranges(n_gates, T, [&](unsigned t, uint64_t gb, uint64_t ge) {
+            for (uint64_t g = gb; g < ge; ++g) {
+                const uint64_t nw = wire_ofs[g + 1] - wire_ofs[g];
+                const bool has_tok = tok_ofs[2 * g + 2] > tok_ofs[2 * g];
+                if (kind[g] == ACX_GATE_MUL) {
+                    if (nw != 1) { err[t] = "Mul gate needs exactly one wire"; return; }
+                    for (int side = 0; side < 2; ++side) {
+                        uint64_t pos = tok_ofs[2 * g + side];
+                        if (!check_tree(pos, tok_ofs[2 * g + side + 1], gl) || pos != tok_ofs[2 * g + side + 1]) {
+                            err[t] = "malformed affine token stream"; return;
+                        }
                     }
-                }
-            } else if (kind[g] == ACX_GATE_EQUAL) {
-                if (nw != 3 || has_tok) { msg = "Equal gate needs three wires"; return ACX_ERR_BAD_CIRCUIT; }
-            } else if (kind[g] == ACX_GATE_SPLIT) {
-                if (nw < 1 || has_tok) { msg = "Split gate needs an input wire"; return ACX_ERR_BAD_CIRCUIT; }
-            } else { msg = "unknown gate kind"; return ACX_ERR_BAD_CIRCUIT; }
-        }
+                } else if (kind[g] == ACX_GATE_EQUAL) {
+                    if (nw != 3 || has_tok) { err[t] = "Equal gate needs three wires"; return; }
+                } else if (kind[g] == ACX_GATE_SPLIT) {
+                    if (nw < 1 || has_tok) { err[t] = "Split gate needs an input wire"; return; }
+                } else { err[t] = "unknown gate kind"; return; }
+            }
+        });
+        for (const char* e : err) if (e) { msg = e; return ACX_ERR_BAD_CIRCUIT; }
         if (m() >= 0xffffffffull) { msg = "too many wires"; return ACX_ERR_TOO_LARGE; }
         return ACX_OK;
     }
@@ -192,9 +226,39 @@ public:
     }
 
     // gateToGenQAP over every gate, rows in gate order.
+    // gateToGenQAP for every gate (src/QAP.hs:366-474, 530-539).  Gates are independent: worker threads take contiguous gate
+    // ranges, build their rows privately and copy them to their final offsets (rows stay in gate order).
     void build_rows(HostCsr& A, HostCsr& B, HostCsr& C) const {
+        const unsigned T = host_threads(n_gates, 1 << 13);
+        if (T <= 1) { build_rows_range(0, n_gates, A, B, C); return; }
+        std::vector<HostCsr> part[3] = {std::vector<HostCsr>(T), std::vector<HostCsr>(T), std::vector<HostCsr>(T)};
+        parallel_ranges(n_gates, T, [&](unsigned t, uint64_t gb, uint64_t ge) { build_rows_range(gb, ge, part[0][t], part[1][t], part[2][t]); });
+        HostCsr* out[3] = {&A, &B, &C};
+        std::vector<uint64_t> row0[3], nz0[3];
+        for (int k = 0; k < 3; ++k) {
+            row0[k].assign(T + 1, 0); nz0[k].assign(T + 1, 0);
+            for (unsigned t = 0; t < T; ++t) {
+                row0[k][t + 1] = row0[k][t] + part[k][t].rowptr.size() - 1;
+                nz0[k][t + 1] = nz0[k][t] + part[k][t].col.size();
+            }
+            out[k]->rowptr.assign(row0[k][T] + 1, 0);
+            out[k]->col.resize(nz0[k][T]);
+            out[k]->val.resize(nz0[k][T]);
+        }
+        parallel_ranges(T, T, [&](unsigned t, uint64_t, uint64_t) {
+            for (int k = 0; k < 3; ++k) {
+                const HostCsr& src = part[k][t];
+                std::copy(src.col.begin(), src.col.end(), out[k]->col.begin() + nz0[k][t]);
+                std::copy(src.val.begin(), src.val.end(), out[k]->val.begin() + nz0[k][t]);
+                for (size_t i = 1; i < src.rowptr.size(); ++i)
+                    out[k]->rowptr[row0[k][t] + i] = (uint32_t)(nz0[k][t] + src.rowptr[i]);
+            }
+        });
+    }
+
+    void build_rows_range(uint64_t g_begin, uint64_t g_end, HostCsr& A, HostCsr& B, HostCsr& C) const {
         const H256 one = hf.one(), minus_one = hf.neg(hf.one()), zero = hf.zero();
-        for (uint64_t g = 0; g < n_gates; ++g) {
+        for (uint64_t g = g_begin; g < g_end; ++g) {
             const acx_wire* gw = &wires[wire_ofs[g]];
             if (kind[g] == ACX_GATE_MUL) {
                 std::map<uint64_t, H256> l, r, o;

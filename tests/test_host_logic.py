@@ -261,3 +261,33 @@ def test_c_host_links_against_the_abi_and_fails_loudly_without_a_gpu(acx, tmp_pa
         assert out.returncode == 0 and "Valid assignment" in out.stdout, out.stderr
     else:
         assert out.returncode == 77 and "no usable HIP device" in out.stderr, (out.returncode, out.stderr)
+
+
+def test_threaded_row_generation_equals_sequential(acx, monkeypatch):
+    """arithCircuitToGenQAP on the host: gate ranges are processed by worker threads (ACX_HOST_THREADS); rows, their
+    order and the witness are identical to the single-threaded result, and a malformed gate deep inside a late range
+    is still reported."""
+    import importlib
+    synth = importlib.import_module("arithmetic-circuits_amd.synth")
+    monkeypatch.setenv("ACX_HOST_THREADS", "1")
+    s1 = synth.mulgraph(1 << 14, n_in=64, window=512, seed=3)
+    rows1, w1 = s1.rows(), s1.witness()
+    monkeypatch.setenv("ACX_HOST_THREADS", "5")              # uneven ranges
+    s5 = synth.mulgraph(1 << 14, n_in=64, window=512, seed=3)
+    rows5, w5 = s5.rows(), s5.witness()
+    for a, b in zip(rows1, rows5):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert np.array_equal(w1, w5)
+    # an unknown gate kind deep in the last of the five ranges: 40 Mul gates Var(i0) * Var(i1) -> mid_g
+    ng = 40
+    kinds = [0] * ng
+    kinds[37] = 7
+    tok_ofs = list(range(0, 2 * ng + 1))                       # one VAR token per side
+    gl, keep = _gate_list(acx, kinds, tok_ofs, [3] * (2 * ng), [0, 1] * ng, [], [[0, 0], [0, 1]],
+                          list(range(ng + 1)), [[1, g] for g in range(ng)])
+    h = C.c_void_p()
+    assert acx._lib.load().acx_circuit_create(0, C.byref(gl), C.byref(h)) == acx._lib.STATUS["BAD_CIRCUIT"]
+    keep[0][37] = 0                                            # repaired: accepted
+    lib = acx._lib.load()
+    assert lib.acx_circuit_create(0, C.byref(gl), C.byref(h)) == 0
+    lib.acx_circuit_destroy(h)
