@@ -173,3 +173,11 @@ def qapset_to_flat(qs: R.QapSet, dims, p: int) -> List[int]:
 
 def csr_equal(a, b) -> bool:
     return all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+
+
+def free_port() -> int:
+    """A TCP port that is free right now on 127.0.0.1 (torch.distributed rendezvous of the multi-process tests)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

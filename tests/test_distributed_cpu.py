@@ -8,8 +8,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,port", [(2, 29621), (4, 29622)])
-def test_sharded_verify_and_distributed_ntt_gloo(world, port):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_verify_and_distributed_ntt_gloo(world):
+    from tests.helpers import free_port
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
     env = dict(os.environ, OMP_NUM_THREADS="1")

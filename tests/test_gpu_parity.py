@@ -841,7 +841,7 @@ def test_bench_two_ranks_on_one_device():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ACX_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20",
+           "--master-port", str(H.free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20",
            "--warmup", "3", "--copies", "4", "--no-cpu", "--no-ntt", "--dist-logn", "18"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -866,7 +866,7 @@ def test_bench_force_dist_rccl_one_rank():
     _need_gpu()
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29619", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(H.free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "3",
            "--copies", "4", "--no-cpu", "--no-ntt", "--dist-logn", "18"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
@@ -885,7 +885,7 @@ def test_sharded_layer_two_ranks_on_one_device():
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29618", os.path.join(root, "tests", "dist_worker_gpu.py")]
+           "--master-port", str(H.free_port()), os.path.join(root, "tests", "dist_worker_gpu.py")]
     out = subprocess.run(cmd, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "dist gpu worker ok 2" in out.stdout
