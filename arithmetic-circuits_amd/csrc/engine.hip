@@ -175,6 +175,8 @@ struct acx_r1cs {
     uint32_t n_slices = 0, n_long = 0;
     // device evaluation plan (present when the system was built from a single-assignment circuit)
     bool has_plan = false;
+    const acx_circuit* plan_src = nullptr;           // circuit the plan will be derived from on first acx_r1cs_eval (holds a reference)
+    std::vector<uint64_t> plan_order;                // root order the rows were loaded in
     std::vector<uint32_t> plan_level_ofs;
     std::vector<uint8_t> plan_written, plan_kind;   // host copies for argument checks
     std::vector<uint32_t> plan_eq_split_inputs;     // flat input wire of every Equal / Split gate
@@ -209,7 +211,13 @@ struct acx_circuit {
     int field = 0;
     HostCircuit hc;
     HostCsr rows[3];     // gateToGenQAP rows in gate order, built once
+    // A system built from this circuit derives its device evaluation plan (acx_r1cs_eval) lazily, on first use, and
+    // holds a reference until then: acx_circuit_destroy releases the rows at once and the gate list with the last reference.
+    mutable std::atomic<int> refs{1};
 };
+static void circuit_release(const acx_circuit* c) {
+    if (c && c->refs.fetch_sub(1) == 1) delete c;
+}
 
 namespace {
 
@@ -851,7 +859,7 @@ int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned
 // Host side of the SELL-64 layout: row order (sorted by length inside windows), slot offsets, and
 // the list of rows that stay in CSR.  Only row lengths are needed; the entries are gathered on
 // the device by k_build_sell from the already converted CSR.
-int build_sell(acx_r1cs* r, const std::vector<uint32_t> rowptr[3]) {
+int build_sell(acx_r1cs* r, const uint32_t* const rowptr[3]) {
     acx_ctx* c = r->ctx;
     const uint64_t n = r->n;
     const uint32_t n_slices = (uint32_t)((n + kSlice - 1) / kSlice);
@@ -969,7 +977,7 @@ int normalise_csr(const HostField& hf, uint64_t n, uint64_t m, const acx_csr* in
     std::vector<std::pair<uint32_t, uint64_t>> tmp;
     for (uint64_t i = 0; i < n; ++i) {
         const uint32_t e0 = in->rowptr[i], e1 = in->rowptr[i + 1];
-        if (e1 < e0) return fail(ACX_ERR_INVALID_ARG, "rowptr not monotone");
+        if (e1 < e0 || e1 > nnz) return fail(ACX_ERR_INVALID_ARG, "rowptr not monotone");
         bool sorted = true;
         for (uint32_t e = e0; e < e1; ++e) {
             if (in->col[e] >= m) return fail(ACX_ERR_INVALID_ARG, "column index >= m");
@@ -1003,18 +1011,18 @@ int normalise_csr(const HostField& hf, uint64_t n, uint64_t m, const acx_csr* in
     return ACX_OK;
 }
 
-int upload_matrix(acx_ctx* c, const std::vector<uint32_t>& ptr, const std::vector<uint32_t>& idx,
+int upload_matrix(acx_ctx* c, const uint32_t* ptr, size_t n_ptr, const uint32_t* idx, size_t nnz,
                   const acx_fr* val, bool convert, DevMatrix& out) {
-    out.nnz = idx.size();
-    HIP_TRY(hipMalloc((void**)&out.ptr, ptr.size() * 4));
-    HIP_TRY(hipMalloc((void**)&out.idx, std::max<size_t>(idx.size(), 1) * 4));
-    HIP_TRY(hipMalloc((void**)&out.val, std::max<size_t>(idx.size(), 1) * 32));
-    HIP_TRY(hipMemcpyAsync(out.ptr, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
-    if (!idx.empty()) HIP_TRY(hipMemcpyAsync(out.idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
+    out.nnz = nnz;
+    HIP_TRY(hipMalloc((void**)&out.ptr, n_ptr * 4));
+    HIP_TRY(hipMalloc((void**)&out.idx, std::max<size_t>(nnz, 1) * 4));
+    HIP_TRY(hipMalloc((void**)&out.val, std::max<size_t>(nnz, 1) * 32));
+    HIP_TRY(hipMemcpyAsync(out.ptr, ptr, n_ptr * 4, hipMemcpyHostToDevice, cur_stream(c)));
+    if (nnz) HIP_TRY(hipMemcpyAsync(out.idx, idx, nnz * 4, hipMemcpyHostToDevice, cur_stream(c)));
     if (convert) {
-        ACX_TRY(upload_elements(c, val, idx.size(), out.val));
+        ACX_TRY(upload_elements(c, val, nnz, out.val));
     } else {
-        if (!idx.empty()) HIP_TRY(hipMemcpyAsync(out.val, val, idx.size() * 32, hipMemcpyHostToDevice, cur_stream(c)));
+        if (nnz) HIP_TRY(hipMemcpyAsync(out.val, val, nnz * 32, hipMemcpyHostToDevice, cur_stream(c)));
         HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     }
     return ACX_OK;
@@ -1064,24 +1072,50 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
     int rc = ACX_OK;
     PhaseTimer pt;
     try {                                              // host vectors are sized by caller data
-        std::vector<uint32_t> rowptrs[3];
+        // A matrix whose rows arrive sorted by column without duplicates (what every producer in this repository and the
+        // Haskell marshaller emit) is used in place: validated by worker threads, uploaded straight from the caller's
+        // arrays.  Anything else is sorted / merged into a private copy first.
+        std::vector<uint32_t> own_rowptr[3], own_col[3];
+        std::vector<acx_fr> own_val[3];
+        const uint32_t* rowptrs[3] = {nullptr, nullptr, nullptr};
         for (int k = 0; k < 3 && rc == ACX_OK; ++k) {
-            std::vector<uint32_t>& rowptr = rowptrs[k];
-            std::vector<uint32_t> col;
-            std::vector<acx_fr> val;
-            rc = normalise_csr(ctx->hf, n, m, mats[k], rowptr, col, val);
-            pt.mark("normalise_csr");
+            const acx_csr* in = mats[k];
+            if (!in || !in->rowptr) { rc = fail(ACX_ERR_INVALID_ARG, "null CSR"); break; }
+            const uint32_t* rowptr = in->rowptr;
+            const uint32_t* col = in->col;
+            const acx_fr* val = in->val;
+            const uint64_t nnz_in = in->rowptr[n];
+            if (in->rowptr[0] != 0) { rc = fail(ACX_ERR_INVALID_ARG, "rowptr[0] != 0"); break; }
+            if (nnz_in && (!in->col || !in->val)) { rc = fail(ACX_ERR_INVALID_ARG, "null CSR arrays"); break; }
+            std::atomic<int> state{0};                         // 0 in place, 1 needs normalising, 2 invalid (reported by normalise_csr)
+            parallel_ranges(n, host_threads(n, 1 << 16), [&](unsigned, uint64_t b, uint64_t e) {
+                for (uint64_t i = b; i < e && state.load(std::memory_order_relaxed) == 0; ++i) {
+                    const uint32_t e0 = rowptr[i], e1 = rowptr[i + 1];
+                    if (e1 < e0 || e1 > nnz_in) { state = 2; return; }
+                    for (uint32_t q = e0; q < e1; ++q) {
+                        if (col[q] >= m) { state = 2; return; }
+                        if (q > e0 && col[q] <= col[q - 1]) { state = 1; return; }
+                    }
+                }
+            });
+            if (state != 0) {
+                rc = normalise_csr(ctx->hf, n, m, in, own_rowptr[k], own_col[k], own_val[k]);
+                rowptr = own_rowptr[k].data(); col = own_col[k].data(); val = own_val[k].data();
+            }
+            rowptrs[k] = rowptr;
+            const uint64_t nnz = rc == ACX_OK ? rowptr[n] : 0;
+            pt.mark("validate / normalise");
             if (rc == ACX_OK && k == 2) {
                 static const uint8_t one32[32] = {1};
                 bool unit = true;
-                for (size_t e = 0; e < val.size() && unit; ++e) unit = std::memcmp(val[e].b, one32, 32) == 0;
+                for (uint64_t e = 0; e < nnz && unit; ++e) unit = std::memcmp(val[e].b, one32, 32) == 0;
                 r->unit_c = unit;
             }
             // small-coefficient form (kernels.hip.h sell_dot_small): every entry of the rows this matrix keeps in SELL
             // is c or p - c with c <= 2^27.  Rows longer than the SELL cut-over go through the CSR kernel whatever
             // they hold (Split gates: powers of two up to 2^255), so they do not count.
             if (rc == ACX_OK && ctx->small_coeff && !(k == 2 && r->unit_c)) {
-                bool small = !val.empty();
+                bool small = nnz != 0;
                 for (uint64_t i = 0; i < n && small; ++i) {
                     const uint32_t e0 = rowptr[i], e1 = rowptr[i + 1];
                     if (e1 - e0 > (uint32_t)kSellMaxLen) continue;
@@ -1090,7 +1124,7 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
                 if (small) r->small |= 1u << k;
             }
             pt.mark("classify");
-            if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, col, val.data(), true, r->M[k]);
+            if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, n + 1, col, nnz, val, true, r->M[k]);
             pt.mark("upload_matrix");
         }
         if (rc == ACX_OK) rc = build_sell(r, rowptrs);
@@ -1312,7 +1346,11 @@ int acx_circuit_check_root_counts(const acx_circuit* c, const uint32_t* counts, 
     return ACX_OK;
 }
 
-void acx_circuit_destroy(acx_circuit* c) { delete c; }
+void acx_circuit_destroy(acx_circuit* c) {
+    if (!c) return;
+    for (auto& m : c->rows) { HostCsr empty; std::swap(m, empty); }      // the rows are never needed by a pending plan
+    circuit_release(c);
+}
 
 int acx_circuit_dims(const acx_circuit* c, uint64_t* n_rows, uint64_t* m_wires, uint64_t* n_inputs,
                      uint64_t* n_intermediates, uint64_t* n_outputs) {
@@ -1419,12 +1457,29 @@ static int circuit_to_r1cs_impl(acx_ctx* ctx, const acx_circuit* c, const acx_fr
     PhaseTimer pt;
     ACX_TRY(r1cs_from_host(ctx, hc.n_rows(), hc.m(), mats, out));
     pt.mark("r1cs_from_host total");
-    struct AtExit { PhaseTimer& p; ~AtExit() { p.mark("evaluation plan"); } } at_exit{pt};
-    // device evaluation plan (generateAssignment on the GPU), when the circuit allows it
+    // the device evaluation plan (generateAssignment on the GPU) is derived on first use: a caller that only verifies
+    // never pays for it (28 ms of levelling per 2^20 gates)
+    (*out)->plan_src = c;
+    c->refs.fetch_add(1);
+    (*out)->plan_order = std::move(order);
+    return ACX_OK;
+}
+
+// Levels, per-gate records and their device copies for acx_r1cs_eval; the caller holds ctx->mu.  Failure is not an error of
+// the system: acx_r1cs_eval then reports ACX_ERR_UNSUPPORTED and the host evaluator (acx_circuit_eval) remains.
+static void ensure_eval_plan(acx_r1cs* r) {
+    if (!r->plan_src) return;
+    const acx_circuit* src = r->plan_src;
+    r->plan_src = nullptr;
+    const HostCircuit& hc = src->hc;
+    const std::vector<uint64_t> order = std::move(r->plan_order);
+    acx_ctx* ctx = r->ctx;
+    PhaseTimer pt;
+    struct Release { const acx_circuit* c; ~Release() { circuit_release(c); } } release{src};
+    try {
     HostCircuit::EvalPlan plan;
     if (hc.n_gates > 0 && hc.n_gates < 0xffffffffull && hc.build_plan(plan)) {
-        acx_r1cs* r = *out;
-        CtxLock lock(ctx->mu);
+        pt.mark("  plan: levels");
         const uint64_t ng = hc.n_gates;
         std::vector<uint32_t> inv(hc.n_rows());
         if (order.empty()) for (uint64_t i = 0; i < inv.size(); ++i) inv[i] = (uint32_t)i;
@@ -1439,12 +1494,14 @@ static int circuit_to_r1cs_impl(acx_ctx* ctx, const acx_circuit* c, const acx_fr
         }
         wofs[ng] = (uint32_t)hc.wire_ofs[ng];
         for (size_t i = 0; i < hc.wires.size(); ++i) wflat[i] = (uint32_t)hc.flat(hc.wires[i]);
+        pt.mark("  plan: gate arrays");
         // level-ordered records of the Mul gates (entry ranges of their A and B rows in the device CSR)
         std::vector<uint32_t> ptr_a(hc.n_rows() + 1), ptr_b(hc.n_rows() + 1);
         // the plan is an optimisation: if anything below fails the system is still valid, only acx_r1cs_eval is not offered
         if (hipMemcpy(ptr_a.data(), r->M[0].ptr, ptr_a.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(ptr_b.data(), r->M[1].ptr, ptr_b.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
-            return ACX_OK;
+            return;
+        pt.mark("  plan: rowptr download");
         std::vector<uint32_t> mul(plan.items.size() * 4, 0xffffffffu);
         for (size_t t = 0; t < plan.items.size(); ++t) {
             const uint32_t g = plan.items[t];
@@ -1456,6 +1513,7 @@ static int circuit_to_r1cs_impl(acx_ctx* ctx, const acx_circuit* c, const acx_fr
             mul[4 * t + 2] = ptr_b[ri];
             mul[4 * t + 3] = na | (nb << 16);
         }
+        pt.mark("  plan: mul records");
         auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
             return hipMalloc(dst, bytes ? bytes : 4) == hipSuccess && (bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
         };
@@ -1468,9 +1526,11 @@ static int circuit_to_r1cs_impl(acx_ctx* ctx, const acx_circuit* c, const acx_fr
             r->plan_n_in = hc.n_in;
         }
     }
-    return ACX_OK;
+    } catch (const std::bad_alloc&) {
+        r->has_plan = false;
+    }
+    pt.mark("evaluation plan (lazy)");
 }
-
 
 int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_r1cs** out) {
     if (!ctx || !c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
@@ -1493,6 +1553,7 @@ void acx_r1cs_destroy(acx_r1cs* r) {
         (void)hipDeviceSynchronize();        // every lane: nothing may still be using this object
         free_r1cs_device(r);
     }
+    circuit_release(r->plan_src);
     delete r;
 }
 
@@ -1615,12 +1676,13 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
 int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs, acx_fr* witness,
                   uint8_t* assigned) {
     if (!r || (n_inputs && !inputs)) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (!r->has_plan)
-        return fail(ACX_ERR_UNSUPPORTED, "no device evaluation plan (system not built from a single-assignment circuit)");
     acx_ctx* c = r->ctx;
     const HostField& hf = c->hf;
     CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    ensure_eval_plan(r);
+    if (!r->has_plan)
+        return fail(ACX_ERR_UNSUPPORTED, "no device evaluation plan (system not built from a single-assignment circuit)");
     // which wires hold a value afterwards (what the QapSet would contain)
     std::vector<uint8_t> as(r->plan_written);
     const uint64_t n_use = std::min<uint64_t>(n_inputs, r->plan_n_in);

@@ -679,6 +679,14 @@ def test_gpu_witness_generation_mulgraph_and_errors(request, acx):
     for g in (0, 1, 17, 4095, (1 << 14) - 1):
         dot = lambda M: sum(int(v) * wi[int(c)] for c, v in zip(M[1][M[0][g]:M[0][g + 1]], acx.fr_to_ints(M[2][M[0][g]:M[0][g + 1]]))) % ctx.p
         assert wi[int(_C[1][_C[0][g]])] == dot(A) * dot(B) % ctx.p
+    # the evaluation plan is derived on first use; the system keeps what it needs of the circuit alive until then
+    s2 = synth.mulgraph(1 << 12, n_in=64, window=512, seed=78)
+    r2 = s2.circuit.to_r1cs(ctx)
+    want2 = s2.witness()
+    s2.circuit.close()                                        # acx_circuit_destroy before the first acx_r1cs_eval
+    w2x, _ = r2.eval_witness(s2.inputs)
+    assert np.array_equal(w2x, want2) and r2.verify_resident()[0]
+    r2.close()
     # partially present inputs: absent keys read as 0 (fromMaybe 0, src/Circuit/Affine.hs:84)
     pres = np.ones(64, dtype=np.uint8)
     pres[3] = 0
