@@ -121,7 +121,11 @@ void* acx_ctx_stream(acx_ctx* ctx);
 /* Pure host code: needs no device.  Copies and validates a marshalled gate list over the given
  * acx_field.  Wire numbering is fixed here:
  * num_inputs / num_intermediates / num_outputs = max index + 1 over every wire the circuit
- * mentions (src/QAP.hs:605-620 applies the same rule to the assignment's key sets). */
+ * mentions (src/QAP.hs:605-620 applies the same rule to the assignment's key sets).  Validation, the Montgomery
+ * conversion of the scalars and the rows of every gate (gateToGenQAP) are computed here, over gate ranges on the host's
+ * cores (ACX_HOST_THREADS overrides the thread count).
+ * acx_circuit_destroy may be called at any time: systems built from the circuit stay valid (they keep what their
+ * evaluation plan needs referenced until it has been derived). */
 int acx_circuit_create(int field, const acx_gate_list* gates, acx_circuit** out);
 void acx_circuit_destroy(acx_circuit* c);
 int acx_circuit_dims(const acx_circuit* c, uint64_t* n_rows, uint64_t* m_wires,
@@ -199,7 +203,8 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
  * reuse their own constraint rows.  Available for systems built by acx_circuit_to_r1cs from a
  * circuit in single-assignment form (else ACX_ERR_UNSUPPORTED: use acx_circuit_eval).  Same
  * arguments and results as acx_circuit_eval; witness/assigned may be NULL.  The witness also stays
- * resident on the device for acx_r1cs_verify_resident. */
+ * resident on the device for acx_r1cs_verify_resident.  The plan (levels, per-gate records) is derived on the first
+ * call, not at load: a caller that only verifies never pays for it. */
 int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs,
                   acx_fr* witness, uint8_t* assigned);
 /* verifyAssignment of the witness left on the device by acx_r1cs_eval. */
