@@ -833,7 +833,7 @@ int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out) {
     if (r->n_long == 0) return ACX_OK;
     CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val},
         C{r->M[2].ptr, r->M[2].idx, r->M[2].val};
-    const int grid = (int)((r->n_long + kBlock - 1) / kBlock);
+    const int grid = (int)((r->n_long + kBlock / kSlice - 1) / (kBlock / kSlice));      // one wave per long row
     DISPATCH_FIELD(c, {
         if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual_rows<F, true>), dim3(grid), dim3(kBlock), 0, cur_stream(c), A, B, C,
                                           d_w, (const u32*)r->long_rows, r->n_long, out);

@@ -359,23 +359,68 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
 }
 
-// CSR path for the listed rows only (rows too long for the SELL layout).
+// CSR path for the listed rows only (rows too long for the SELL layout: the 2^j row of a Split gate has 257 entries,
+// src/QAP.hs:447-459).  ONE WAVE PER ROW: lane l takes entries e0 + l, e0 + l + 64, ... (coalesced column / value loads),
+// sums up to kWideTerms raw products per deferred reduction, and the 64 partial sums are folded with xor-shuffles.
+// (One LANE per row -- the first version -- walked 257 dependent gathers serially: 150 us for the 87 long rows of a
+// 6000-gate circuit in the reference's 50:10:1 gate mix, 95 % of its verification.)
+template <class F, bool UNIT>
+__device__ __forceinline__ Fe long_row_dot(const CsrDev& M, const uint4* __restrict__ w, u32 row, u32 lane) {
+    const u32 e0 = M.rowptr[row], e1 = M.rowptr[row + 1];
+    Fe acc = fe_zero();
+    bool any = false;
+    for (u32 base = e0 + lane; base < e1; base += kSlice * kWideTerms) {
+        Fe part = fe_zero();
+        if (UNIT) {
+            bool first = true;
+#pragma unroll 1
+            for (int j = 0; j < kWideTerms; ++j) {
+                const u32 e = base + kSlice * j;
+                if (e < e1) {
+                    const Fe x = fe_load(w + 2 * (u64)M.col[e]);
+                    part = first ? x : fe_add<F>(part, x);
+                    first = false;
+                }
+            }
+        } else {
+            Wide wide;
+            wide_zero(wide);
+#pragma unroll 1
+            for (int j = 0; j < kWideTerms; ++j) {
+                const u32 e = base + kSlice * j;
+                if (e < e1) wide_mac(wide, fe_load(M.val + 2 * (u64)e), fe_load(w + 2 * (u64)M.col[e]));
+            }
+            part = wide_reduce<F>(wide);
+        }
+        acc = any ? fe_add<F>(acc, part) : part;
+        any = true;
+    }
+#pragma unroll 1
+    for (int off = kSlice / 2; off > 0; off >>= 1) {
+        Fe o;
+#pragma unroll
+        for (int k = 0; k < kLimbs; ++k) o.l[k] = (u32)__shfl_xor((int)acc.l[k], off, kSlice);
+        acc = fe_add<F>(acc, o);
+    }
+    return acc;                                                   // every lane holds the row's dot product
+}
+
 template <class F, bool UNIT_C>
 __global__ __launch_bounds__(kBlock) void k_r1cs_residual_rows(CsrDev A, CsrDev B, CsrDev C,
                                                               const uint4* __restrict__ w,
                                                               const u32* __restrict__ rows, u32 n_rows,
                                                               ResidualOut out) {
-    const u32 i = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = i < n_rows;
+    const u32 i = blockIdx.x * (kBlock / kSlice) + threadIdx.x / kSlice, lane = threadIdx.x % kSlice;
+    const bool have = i < n_rows;                                // wave-uniform
     Fe a = fe_zero(), b = a, c = a;
     u32 row = kNoRow;
-    if (live) {
+    if (have) {
         row = rows[i];
-        a = csr_row_dot<F, false>(A, w, row);
-        b = csr_row_dot<F, false>(B, w, row);
-        c = csr_row_dot<F, UNIT_C>(C, w, row);
+        a = long_row_dot<F, false>(A, w, row, lane);
+        b = long_row_dot<F, false>(B, w, row, lane);
+        c = long_row_dot<F, UNIT_C>(C, w, row, lane);
     }
-    residual_epilogue<F>(a, b, c, row, live, out);
+    residual_epilogue<F>(a, b, c, row, have && lane == 0, out);
 }
 
 // ---------------------------------------------------------------------------------------------
