@@ -25,3 +25,21 @@ torch.cuda.synchronize()
 us = kbench.time_stream(stream, lambda: r.verify_dev(dw.data_ptr(), res.data_ptr()), 200)
 nnz = sum(int(m[0][-1]) for m in circ.rows())
 print(f"{len(gates)} gates -> n = {r.n} rows, nnz = {nnz}, format {r.format()}: verify_dev {us:.1f} us")
+import time
+inp = acx.ints_to_fr([rnd.randrange(ctx.p) for _ in range(6)])
+r.eval_witness(inp)
+t0 = time.perf_counter()
+for _ in range(5):
+    wg, _ = r.eval_witness(inp)
+t_gpu = (time.perf_counter() - t0) / 5
+t0 = time.perf_counter()
+for _ in range(5):
+    wh, _ = circ.eval(inp)
+t_host = (time.perf_counter() - t0) / 5
+assert np.array_equal(wg, wh)
+print(f"generateAssignment: GPU (acx_r1cs_eval, incl. D2H of the witness) {t_gpu * 1e3:.2f} ms, host (acx_circuit_eval) {t_host * 1e3:.2f} ms; levels: see ACX trace")
+h, ok = r.qap_h(wh)
+t0 = time.perf_counter()
+for _ in range(5):
+    r.qap_h(wh)
+print(f"qap_h (host buffers): {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms, ok={ok}")
