@@ -158,6 +158,8 @@ struct DevMatrix {
     uint64_t nnz = 0;
 };
 
+constexpr int kRowTiers = 4;
+
 struct acx_r1cs {
     acx_ctx* ctx = nullptr;
     uint64_t n = 0, m = 0;
@@ -173,6 +175,7 @@ struct acx_r1cs {
     u32* perm = nullptr;
     u32* long_rows = nullptr;
     uint32_t n_slices = 0, n_long = 0;
+    uint32_t tier_rows[4] = {0, 0, 0, 0};               // long_rows by length tier: <= 12, <= 24, <= 48 entries, longer
     // device evaluation plan (present when the system was built from a single-assignment circuit)
     bool has_plan = false;
     const acx_circuit* plan_src = nullptr;           // circuit the plan will be derived from on first acx_r1cs_eval (holds a reference)
@@ -833,14 +836,24 @@ int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out) {
     if (r->n_long == 0) return ACX_OK;
     CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val},
         C{r->M[2].ptr, r->M[2].idx, r->M[2].val};
-    const int grid = (int)((r->n_long + kBlock / kSlice - 1) / (kBlock / kSlice));      // one wave per long row
-    DISPATCH_FIELD(c, {
-        if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual_rows<F, true>), dim3(grid), dim3(kBlock), 0, cur_stream(c), A, B, C,
-                                          d_w, (const u32*)r->long_rows, r->n_long, out);
-        else hipLaunchKernelGGL((k_r1cs_residual_rows<F, false>), dim3(grid), dim3(kBlock), 0, cur_stream(c), A, B, C,
-                                d_w, (const u32*)r->long_rows, r->n_long, out);
-    });
-    HIP_TRY(hipGetLastError());
+    // long_rows holds the tiers one after the other (build_sell): <= 12, <= 24, <= 48 entries, longer
+    static const uint32_t lanes[kRowTiers] = {2, 4, 8, 8};
+    uint32_t first = 0;
+    for (int t = 0; t < kRowTiers; ++t) {
+        const uint32_t count = r->tier_rows[t];
+        if (count == 0) continue;
+        // many long rows: throughput matters, and eight lanes with several reductions each cost fewer instructions per row
+        // than a wave with one; a few (the Split gates of a circuit) are a latency problem and take a wave per row
+        const uint32_t G = (t == kRowTiers - 1 && count < 4096) ? (uint32_t)kSlice : lanes[t];
+        const dim3 grid((unsigned)(((uint64_t)count * G + kBlock - 1) / kBlock));
+        const u32* rows = (const u32*)r->long_rows + first;
+        DISPATCH_FIELD(c, {
+            if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual_rows<F, true>), grid, dim3(kBlock), 0, cur_stream(c), A, B, C, d_w, rows, count, G, out);
+            else hipLaunchKernelGGL((k_r1cs_residual_rows<F, false>), grid, dim3(kBlock), 0, cur_stream(c), A, B, C, d_w, rows, count, G, out);
+        });
+        HIP_TRY(hipGetLastError());
+        first += count;
+    }
     return ACX_OK;
 }
 
@@ -866,7 +879,7 @@ int build_sell(acx_r1cs* r, const uint32_t* const rowptr[3]) {
     r->n_slices = n_slices;
     if (n == 0) return ACX_OK;
     PhaseTimer pt;
-    std::vector<uint32_t> key(n), perm((size_t)n_slices * kSlice, kNoRow), longs;
+    std::vector<uint32_t> key(n), perm((size_t)n_slices * kSlice, kNoRow), longs, tiers[kRowTiers];
     // Row classes: (lenA, lenB, lenC) with every length <= kSellMaxLen, or "long".  Few classes, so the stable sort of a
     // window is a counting sort (a comparison sort of 2^20 rows cost 32 ms of a 110 ms load).
     constexpr uint32_t kLenRadix = kSellMaxLen + 1, kLongClass = kLenRadix * kLenRadix * kLenRadix;
@@ -875,7 +888,14 @@ int build_sell(acx_r1cs* r, const uint32_t* const rowptr[3]) {
         bool is_long = false;
         for (int k = 0; k < 3; ++k) { l[k] = rowptr[k][i + 1] - rowptr[k][i]; is_long = is_long || l[k] > (uint32_t)kSellMaxLen; }
         key[i] = is_long ? kLongClass : (l[0] * kLenRadix + l[1]) * kLenRadix + l[2];
-        if (is_long) longs.push_back((uint32_t)i);
+        if (is_long) {
+            const uint32_t mx = std::max({l[0], l[1], l[2]});
+            tiers[mx <= 2 * kWideTerms ? 0 : mx <= 4 * kWideTerms ? 1 : mx <= 8 * kWideTerms ? 2 : 3].push_back((uint32_t)i);
+        }
+    }
+    for (int t = 0; t < kRowTiers; ++t) {
+        r->tier_rows[t] = (uint32_t)tiers[t].size();
+        longs.insert(longs.end(), tiers[t].begin(), tiers[t].end());
     }
     std::vector<uint32_t> start(kLongClass + 2);
     for (uint64_t ws = 0; ws < n; ws += kSellWindow) {

@@ -365,17 +365,17 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
 // (One LANE per row -- the first version -- walked 257 dependent gathers serially: 150 us for the 87 long rows of a
 // 6000-gate circuit in the reference's 50:10:1 gate mix, 95 % of its verification.)
 template <class F, bool UNIT>
-__device__ __forceinline__ Fe long_row_dot(const CsrDev& M, const uint4* __restrict__ w, u32 row, u32 lane) {
+__device__ __forceinline__ Fe long_row_dot(const CsrDev& M, const uint4* __restrict__ w, u32 row, u32 sub, u32 G) {
     const u32 e0 = M.rowptr[row], e1 = M.rowptr[row + 1];
     Fe acc = fe_zero();
     bool any = false;
-    for (u32 base = e0 + lane; base < e1; base += kSlice * kWideTerms) {
+    for (u32 base = e0 + sub; base < e1; base += G * kWideTerms) {
         Fe part = fe_zero();
         if (UNIT) {
             bool first = true;
 #pragma unroll 1
             for (int j = 0; j < kWideTerms; ++j) {
-                const u32 e = base + kSlice * j;
+                const u32 e = base + G * j;
                 if (e < e1) {
                     const Fe x = fe_load(w + 2 * (u64)M.col[e]);
                     part = first ? x : fe_add<F>(part, x);
@@ -387,7 +387,7 @@ __device__ __forceinline__ Fe long_row_dot(const CsrDev& M, const uint4* __restr
             wide_zero(wide);
 #pragma unroll 1
             for (int j = 0; j < kWideTerms; ++j) {
-                const u32 e = base + kSlice * j;
+                const u32 e = base + G * j;
                 if (e < e1) wide_mac(wide, fe_load(M.val + 2 * (u64)e), fe_load(w + 2 * (u64)M.col[e]));
             }
             part = wide_reduce<F>(wide);
@@ -396,31 +396,32 @@ __device__ __forceinline__ Fe long_row_dot(const CsrDev& M, const uint4* __restr
         any = true;
     }
 #pragma unroll 1
-    for (int off = kSlice / 2; off > 0; off >>= 1) {
+    for (int off = (int)G / 2; off > 0; off >>= 1) {              // fold the G partial sums of the row's lane group
         Fe o;
 #pragma unroll
         for (int k = 0; k < kLimbs; ++k) o.l[k] = (u32)__shfl_xor((int)acc.l[k], off, kSlice);
         acc = fe_add<F>(acc, o);
     }
-    return acc;                                                   // every lane holds the row's dot product
+    return acc;                                                   // every lane of the group holds the row's dot product
 }
 
+// G lanes per row (a power of two, 2 .. 64; one launch per tier of row lengths): rows of 7 .. 12 entries -- affine sides
+// that are sums of several wires -- take two lanes each and cost about what a SELL row costs, 13 .. 24 four, up to 48 eight;
+// longer rows eight lanes with several reductions per lane when there are many of them (throughput), a whole wave each when
+// there are few (the Split gates of a circuit: latency).
 template <class F, bool UNIT_C>
 __global__ __launch_bounds__(kBlock) void k_r1cs_residual_rows(CsrDev A, CsrDev B, CsrDev C,
                                                               const uint4* __restrict__ w,
-                                                              const u32* __restrict__ rows, u32 n_rows,
+                                                              const u32* __restrict__ rows, u32 n_rows, u32 G,
                                                               ResidualOut out) {
-    const u32 i = blockIdx.x * (kBlock / kSlice) + threadIdx.x / kSlice, lane = threadIdx.x % kSlice;
-    const bool have = i < n_rows;                                // wave-uniform
-    Fe a = fe_zero(), b = a, c = a;
-    u32 row = kNoRow;
-    if (have) {
-        row = rows[i];
-        a = long_row_dot<F, false>(A, w, row, lane);
-        b = long_row_dot<F, false>(B, w, row, lane);
-        c = long_row_dot<F, UNIT_C>(C, w, row, lane);
-    }
-    residual_epilogue<F>(a, b, c, row, have && lane == 0, out);
+    const u32 i = (blockIdx.x * kBlock + threadIdx.x) / G, sub = threadIdx.x % G;
+    const bool have = i < n_rows;
+    // groups past the end run on the last row (uniform control flow for the shuffles) and report nothing
+    const u32 row = rows[have ? i : n_rows - 1];
+    const Fe a = long_row_dot<F, false>(A, w, row, sub, G);
+    const Fe b = long_row_dot<F, false>(B, w, row, sub, G);
+    const Fe c = long_row_dot<F, UNIT_C>(C, w, row, sub, G);
+    residual_epilogue<F>(a, b, c, row, have && sub == 0, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1211,3 +1211,25 @@ def test_device_memory_is_returned(request, acx):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), (free0, free1)
+
+
+def test_many_long_rows_take_the_eight_lane_path(request, acx):
+    """Rows outside the SELL layout are handled in tiers of lanes per row (2 / 4 / 8, a wave for a FEW long rows); more than
+    4096 rows of more than 48 entries take eight lanes with several reductions each.  4300 rows of 49 .. 130 entries in A
+    (1 .. 3 in B, C), residual vector and verdict against the oracle."""
+    ctx, orc = _ctx(request, "bn254"), _orc(request, "bn254")
+    p = ctx.p
+    rs, rnd = np.random.RandomState(11), random.Random(12)
+    n, m = 4300, 700
+    mats = []
+    for k in range(3):
+        lens = rs.randint(49, 131, size=n) if k == 0 else rs.randint(1, 4, size=n)
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        col = np.concatenate([np.sort(rs.choice(m, size=l, replace=False)) for l in lens]).astype(np.uint32)
+        mats.append((rowptr, col, acx.ints_to_fr([rnd.randrange(p) for _ in range(int(rowptr[-1]))])))
+    w = acx.ints_to_fr([1] + [rnd.randrange(p) for _ in range(m - 1)])
+    r = acx.R1CS.load(ctx, n, m, *mats)
+    assert r.format()[2] == n
+    want, nbad, first = orc.r1cs_residuals(n, m, *mats, w, nthreads=8)
+    assert np.array_equal(r.residuals(w), want)
+    assert r.verify(w) == (nbad == 0, nbad, first)
