@@ -831,7 +831,7 @@ inline unsigned sell_grid_x(uint32_t n_slices) {
 }
 
 // rows too long for SELL go through the CSR kernel
-int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out) {
+int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out, const SellSystem* d_many = nullptr, uint32_t n_many = 1) {
     acx_ctx* c = r->ctx;
     if (r->n_long == 0) return ACX_OK;
     CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val},
@@ -845,11 +845,11 @@ int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out) {
         // many long rows: throughput matters, and eight lanes with several reductions each cost fewer instructions per row
         // than a wave with one; a few (the Split gates of a circuit) are a latency problem and take a wave per row
         const uint32_t G = (t == kRowTiers - 1 && count < 4096) ? (uint32_t)kSlice : lanes[t];
-        const dim3 grid((unsigned)(((uint64_t)count * G + kBlock - 1) / kBlock));
+        const dim3 grid((unsigned)(((uint64_t)count * G + kBlock - 1) / kBlock), n_many, 1);
         const u32* rows = (const u32*)r->long_rows + first;
         DISPATCH_FIELD(c, {
-            if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual_rows<F, true>), grid, dim3(kBlock), 0, cur_stream(c), A, B, C, d_w, rows, count, G, out);
-            else hipLaunchKernelGGL((k_r1cs_residual_rows<F, false>), grid, dim3(kBlock), 0, cur_stream(c), A, B, C, d_w, rows, count, G, out);
+            if (r->unit_c) hipLaunchKernelGGL((k_r1cs_residual_rows<F, true>), grid, dim3(kBlock), 0, cur_stream(c), A, B, C, d_w, rows, count, G, out, d_many);
+            else hipLaunchKernelGGL((k_r1cs_residual_rows<F, false>), grid, dim3(kBlock), 0, cur_stream(c), A, B, C, d_w, rows, count, G, out, d_many);
         });
         HIP_TRY(hipGetLastError());
         first += count;
@@ -1676,8 +1676,7 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
                 launch_sell(c, sell_spec(r), grid, d_desc, SellSystem{});
                 HIP_TRY(hipGetLastError());
             }
-            if (r->n_long)
-                for (uint64_t i = 0; i < k; ++i) ACX_TRY(launch_long_rows(r, desc[i].w, desc[i].out));
+            if (r->n_long) ACX_TRY(launch_long_rows(r, nullptr, ResidualOut{}, d_desc, (uint32_t)k));   // one launch per tier for all witnesses
             CallSlot slot;
             HIP_TRY(hipMemcpyAsync(res.data(), d_res, k * 16, hipMemcpyDeviceToHost, cur_stream(c)));
             ACX_TRY(end_call_fetch(c, &slot));

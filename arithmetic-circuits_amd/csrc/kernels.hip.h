@@ -413,7 +413,11 @@ template <class F, bool UNIT_C>
 __global__ __launch_bounds__(kBlock) void k_r1cs_residual_rows(CsrDev A, CsrDev B, CsrDev C,
                                                               const uint4* __restrict__ w,
                                                               const u32* __restrict__ rows, u32 n_rows, u32 G,
-                                                              ResidualOut out) {
+                                                              ResidualOut out, const SellSystem* __restrict__ many) {
+    if (many != nullptr) {                                       // acx_r1cs_verify_many: blockIdx.y = witness of the same system
+        w = many[blockIdx.y].w;
+        out = many[blockIdx.y].out;
+    }
     const u32 i = (blockIdx.x * kBlock + threadIdx.x) / G, sub = threadIdx.x % G;
     const bool have = i < n_rows;
     // groups past the end run on the last row (uniform control flow for the shuffles) and report nothing
