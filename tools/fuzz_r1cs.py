@@ -20,7 +20,7 @@ def main(seeds):
             unit_c = rnd.random() < 0.5
             mats = []
             for k in range(3):
-                maxlen = min(m, rnd.choice([1, 2, 3, 6, 7, 8, 9, 20]))
+                maxlen = min(m, rnd.choice([1, 2, 3, 6, 7, 8, 9, 13, 20, 30, 60, 300]))
                 lens = rs.randint(0, maxlen + 1, size=n)
                 if rnd.random() < 0.2:
                     lens[:] = 0 if rnd.random() < 0.5 else maxlen
