@@ -377,6 +377,107 @@ __device__ __forceinline__ Fe fe_from_mont(const Fe& a) {
     return fe_reduce<F>(fe_mul<F>(a, one));
 }
 
+// ---- inversion by divsteps ---------------------------------------------------------------------------
+// 1/a for a Montgomery residue a (lazy in, lazy out; a != 0), by the Bernstein-Yang division steps in the half-delta
+// formulation (zeta = -(delta + 1/2); 590 steps suffice for any modulus and input below 2^256), in batches of 29 -- the limb
+// width, so that dividing by 2^29 is dropping a limb: 21 rounds of {29 branch-free steps on the low 32 bits of f and g that
+// yield a 2x2 transition matrix with entries below 2^29 in magnitude; the matrix applied to (f, g) exactly and to (d, e)
+// modulo p} with signed 9 x 29-bit limbs.  About 20 000 instructions against 78 000 for a^(p-2) by square-and-multiply
+// (254 squarings + ~127 products), and it is the LATENCY of one inversion that an Equal gate adds to its level of the
+// GPU witness generation (src/Circuit/Arithmetic.hs:117-131).  Checked against big-integer arithmetic by a bit-accurate
+// Python model of this routine before it was written (tests: every Equal gate of the -m gpu suite).
+template <class F>
+__device__ __forceinline__ Fe fe_inv_divsteps(const Fe& a_mont) {
+    using i64 = int64_t;
+    constexpr i32 kM = (i32)kLimbMask;
+    constexpr u32 kPinv = (0u - F::N0) & kLimbMask;                 // p^-1 mod 2^29 (N0 = -p^-1)
+    const Fe c = fe_reduce<F>(a_mont);                              // canonical residue of a R
+    i32 f[kLimbs], g[kLimbs], d[kLimbs], e[kLimbs];
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) { f[k] = (i32)F::P[k]; g[k] = (i32)c.l[k]; d[k] = 0; e[k] = k == 0 ? 1 : 0; }
+    i32 zeta = -1;
+#pragma unroll 1
+    for (int round = 0; round < 21; ++round) {
+        // 29 division steps on the low bits
+        u32 u = 1, v = 0, q = 0, r = 1;
+        u32 fl = (u32)f[0] | ((u32)f[1] << kLimbBits), gl = (u32)g[0] | ((u32)g[1] << kLimbBits);
+#pragma unroll 1
+        for (int i = 0; i < kLimbBits; ++i) {
+            u32 c1 = (u32)(zeta >> 31);                             // zeta < 0
+            const u32 m2 = 0u - (gl & 1u);                          // g odd
+            const u32 x = (fl ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+            gl += x & m2; q += y & m2; r += z & m2;
+            c1 &= m2;
+            zeta = (i32)(((u32)zeta ^ c1) - 1u);
+            fl += gl & c1; u += q & c1; v += r & c1;
+            gl >>= 1; u <<= 1; v <<= 1;
+        }
+        const i64 U = (i32)u, V = (i32)v, Q = (i32)q, R = (i32)r;
+        {   // (d, e) <- (U d + V e, Q d + R e) / 2^29 mod p, both kept in (-2p, p)
+            const i32 sd = d[kLimbs - 1] >> 31, se = e[kLimbs - 1] >> 31;
+            i32 md = ((i32)U & sd) + ((i32)V & se), me = ((i32)Q & sd) + ((i32)R & se);
+            i64 cd = U * d[0] + V * e[0], ce = Q * d[0] + R * e[0];
+            md -= (i32)((kPinv * (u32)cd + (u32)md) & kLimbMask);
+            me -= (i32)((kPinv * (u32)ce + (u32)me) & kLimbMask);
+            cd += (i64)(i32)F::P[0] * md; ce += (i64)(i32)F::P[0] * me;
+            cd >>= kLimbBits; ce >>= kLimbBits;
+#pragma unroll
+            for (int k = 1; k < kLimbs; ++k) {
+                cd += U * d[k] + V * e[k] + (i64)(i32)F::P[k] * md;
+                ce += Q * d[k] + R * e[k] + (i64)(i32)F::P[k] * me;
+                d[k - 1] = (i32)cd & kM; e[k - 1] = (i32)ce & kM;
+                cd >>= kLimbBits; ce >>= kLimbBits;
+            }
+            d[kLimbs - 1] = (i32)cd; e[kLimbs - 1] = (i32)ce;
+        }
+        {   // (f, g) <- (U f + V g, Q f + R g) / 2^29, exactly
+            i64 cf = U * f[0] + V * g[0], cg = Q * f[0] + R * g[0];
+            cf >>= kLimbBits; cg >>= kLimbBits;
+#pragma unroll
+            for (int k = 1; k < kLimbs; ++k) {
+                cf += U * f[k] + V * g[k];
+                cg += Q * f[k] + R * g[k];
+                f[k - 1] = (i32)cf & kM; g[k - 1] = (i32)cg & kM;
+                cf >>= kLimbBits; cg >>= kLimbBits;
+            }
+            f[kLimbs - 1] = (i32)cf; g[kLimbs - 1] = (i32)cg;
+        }
+    }
+    // g = 0, f = +-1, d = +-1/c in (-2p, p): y = sign(f) * d reduced to [0, p)
+    const i32 sf = f[kLimbs - 1] >> 31;                             // f = -1: all limbs 2^29 - 1 and a negative top
+    i32 y[kLimbs];
+    {
+        const i32 neg = d[kLimbs - 1] >> 31;
+        i32 carry = 0;
+#pragma unroll
+        for (int k = 0; k < kLimbs; ++k) {                          // d + (p if d < 0), then the sign of f
+            i32 t = d[k] + ((i32)F::P[k] & neg);
+            t = (t ^ sf) - sf;
+            t += carry;
+            y[k] = k < kLimbs - 1 ? (t & kM) : t;
+            carry = k < kLimbs - 1 ? (t >> kLimbBits) : 0;
+        }
+    }
+    {
+        const i32 neg = y[kLimbs - 1] >> 31;
+        i32 carry = 0;
+#pragma unroll
+        for (int k = 0; k < kLimbs; ++k) {                          // + p once more if the negation made it negative
+            i32 t = y[k] + ((i32)F::P[k] & neg) + carry;
+            y[k] = k < kLimbs - 1 ? (t & kM) : t;
+            carry = k < kLimbs - 1 ? (t >> kLimbBits) : 0;
+        }
+    }
+    Fe yv;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) yv.l[k] = (u32)y[k];
+    Fe r2;
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) r2.l[k] = F::R2[k];
+    // y = (a R)^-1 = a^-1 R^-1 (canonical, possibly in [p, 2p) before the last step: lazy is enough); a^-1 R = y R^2:
+    return fe_mul<F>(fe_mul<F>(yv, r2), r2);
+}
+
 // canonical check on a plain unpacked value: a < p
 template <class F>
 __device__ __forceinline__ bool fe_lt_p(const Fe& a) {

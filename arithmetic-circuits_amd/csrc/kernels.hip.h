@@ -809,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, Cs
     } else if (kd == 1) {                                     // Equal
         const Fe inp = fe_load(w + 2 * (u64)gw[0]);
         const bool z = fe_is_zero<F>(inp);
-        fe_store(w + 2 * (u64)gw[1], z ? fe_zero() : fe_inv_exp<F>(inp, pm2));
+        fe_store(w + 2 * (u64)gw[1], z ? fe_zero() : fe_inv_divsteps<F>(inp));
         fe_store(w + 2 * (u64)gw[2], z ? fe_zero() : fe_one_mont<F>());
     } else {                                                  // Split
         const Fe c = fe_from_mont<F>(fe_load(w + 2 * (u64)gw[0]));

@@ -1233,3 +1233,29 @@ def test_many_long_rows_take_the_eight_lane_path(request, acx):
     want, nbad, first = orc.r1cs_residuals(n, m, *mats, w, nthreads=8)
     assert np.array_equal(r.residuals(w), want)
     assert r.verify(w) == (nbad == 0, nbad, first)
+
+
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+def test_equal_gate_inversion_edge_values(request, acx, field):
+    """The GPU witness generator inverts an Equal gate's input by division steps (fe_inv_divsteps); the host evaluator and
+    the oracle use a^(p-2).  300 Equal gates on inputs 1, 2, 3, p-1, p-2, (p+1)/2, powers of two up to 2^253, 0 and random
+    values: the m wire (the inverse, src/Circuit/Arithmetic.hs:117-131) and the output wire, bit for bit."""
+    ctx = _ctx(request, field)
+    p = ctx.p
+    rnd = random.Random(99)
+    vals = [1, 2, 3, p - 1, p - 2, (p + 1) // 2, 0, 1 << 253, (1 << 200) + 1] + [1 << k for k in range(0, 250, 9)]
+    vals += [rnd.randrange(p) for _ in range(300 - len(vals))]
+    vals = [v % p for v in vals]
+    gates = [acx.Equal(acx.InputWire(i), acx.IntermediateWire(i), acx.OutputWire(i)) for i in range(len(vals))]
+    circ = acx.ArithCircuit(gates).marshal(field)
+    r = circ.to_r1cs(ctx)
+    inp = acx.ints_to_fr(vals)
+    want, want_as = circ.eval(inp)
+    got, got_as = r.eval_witness(inp)
+    assert np.array_equal(got, want) and np.array_equal(got_as, want_as)
+    wi = acx.fr_to_ints(got)
+    n_in = len(vals)
+    for i, v in enumerate(vals):
+        m, out = wi[1 + n_in + i], wi[1 + 2 * n_in + i]
+        assert (m, out) == ((pow(v, -1, p), 1) if v else (0, 0))
+    assert r.verify_resident()[0]
