@@ -1696,7 +1696,6 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
                   uint8_t* assigned) {
     if (!r || (n_inputs && !inputs)) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
-    const HostField& hf = c->hf;
     CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     ensure_eval_plan(r);
@@ -1716,20 +1715,22 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) w0[1 + i] = inputs[i];
     HIP_TRY(hipMemsetAsync(r->d_w, 0, r->m * 32, cur_stream(c)));
     ACX_TRY(upload_elements(c, w0.data(), w0.size(), r->d_w));
-    Exp256 pm2;
-    {
-        H256 ex = hf.modulus();
-        ex.l[0] -= 2;
-        for (int i = 0; i < 8; ++i) pm2.w[i] = (u32)(ex.l[i / 2] >> (32 * (i % 2)));
-    }
     const CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val};
     const size_t n_levels = r->plan_level_ofs.size() - 1;
+    // narrow levels are latency: eight lanes per gate (k_eval_level_lanes); wide ones throughput: a lane per gate
+    static const uint32_t lanes_below = [] { const char* e = getenv("ACX_EVAL_LANES_BELOW"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 32768u; }();
     for (size_t l = 0; l < n_levels; ++l) {
         const uint32_t lo = r->plan_level_ofs[l], cnt = r->plan_level_ofs[l + 1] - lo;
         if (cnt == 0) continue;
         const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo};
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level<F>), dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, cur_stream(c),
-                                             G, A, B, r->d_w, pm2));
+        if (cnt < lanes_below) {
+            const uint32_t per_block = kBlock / kEvalLanes;
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level_lanes<F>), dim3((cnt + per_block - 1) / per_block), dim3(kBlock), 0, cur_stream(c),
+                                                 G, A, B, r->d_w));
+        } else {
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level<F>), dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, cur_stream(c),
+                                                 G, A, B, r->d_w));
+        }
     }
     HIP_TRY(hipGetLastError());
     if (witness) {

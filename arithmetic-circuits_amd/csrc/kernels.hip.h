@@ -784,22 +784,9 @@ struct EvalGates {
     const uint4* mul;        // per item, level order: Mul gate {out wire, first A entry, first B entry, nA | nB << 16}, else .w = ~0
 };
 
+// one gate of any kind on one lane (everything except the recorded Mul gates of a level)
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, CsrDev B, uint4* __restrict__ w,
-                                                      Exp256 pm2) {
-    const u32 t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= G.count) return;
-    // Mul gates (nearly all of a circuit) carry everything in ONE level-ordered record: a level is a
-    // chain of dependent loads -- item -> gate -> row -> row pointers -> entries -> witness -- and costs
-    // its latency, not its bandwidth, so the record cuts the chain to record -> entries -> witness
-    const uint4 it = gload(G.mul + t);
-    if (it.w != 0xffffffffu) {
-        const Fe a = csr_range_dot<F, false>(A, w, it.y, it.y + (it.w & 0xffffu));
-        const Fe b = csr_range_dot<F, false>(B, w, it.z, it.z + (it.w >> 16));
-        fe_store(w + 2 * (u64)it.x, fe_mul<F>(a, b));
-        return;
-    }
-    const u32 g = G.items[t];
+__device__ __forceinline__ void eval_gate_generic(const EvalGates& G, const CsrDev& A, const CsrDev& B, uint4* __restrict__ w, u32 g) {
     const u32* gw = G.wires + G.wire_ofs[g];
     const u32 kd = G.kind[g];
     if (kd == 0) {                                            // Mul
@@ -819,6 +806,71 @@ __global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, Cs
             fe_store(w + 2 * (u64)gw[1 + j], bit ? fe_one_mont<F>() : fe_zero());
         }
     }
+}
+
+// One lane per gate: the form for WIDE levels (throughput: deferred reduction, 81 multiplier instructions per entry).
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, CsrDev B, uint4* __restrict__ w) {
+    const u32 t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= G.count) return;
+    // Mul gates (nearly all of a circuit) carry everything in ONE level-ordered record: item -> gate -> row -> row
+    // pointers -> entries -> witness becomes record -> entries -> witness
+    const uint4 it = gload(G.mul + t);
+    if (it.w != 0xffffffffu) {
+        const Fe a = csr_range_dot<F, false>(A, w, it.y, it.y + (it.w & 0xffffu));
+        const Fe b = csr_range_dot<F, false>(B, w, it.z, it.z + (it.w >> 16));
+        fe_store(w + 2 * (u64)it.x, fe_mul<F>(a, b));
+        return;
+    }
+    eval_gate_generic<F>(G, A, B, w, G.items[t]);
+}
+
+// A NARROW level (the usual case of a deep circuit: ~800 gates per level in mulgraph(2^20, window 4096)) costs its
+// latency, and with one lane per gate that is a chain of ~10 dependent round trips -- record, then column -> witness for
+// each of the ~4.7 entries of the gate's two rows in turn -- plus ~1400 dependent VALU instructions.  Here a Mul gate
+// takes EIGHT lanes: lanes 0-3 one entry each of its A row, lanes 4-7 of its B row (more entries: strided), every lane one
+// full Montgomery product, the partial sums folded by xor-shuffles, lane 0 multiplies and stores.  The chain is record ->
+// {column, value} -> witness, and ~650 instructions.  Other gate kinds run on lane 0 of their group as before.
+constexpr u32 kEvalLanes = 8;
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_eval_level_lanes(EvalGates G, CsrDev A, CsrDev B, uint4* __restrict__ w) {
+    const u32 t = (blockIdx.x * kBlock + threadIdx.x) / kEvalLanes, sub = threadIdx.x % kEvalLanes;
+    const bool live = t < G.count;
+    uint4 it = make_uint4(0u, 0u, 0u, 0xffffffffu);
+    if (live) it = gload(G.mul + t);
+    const bool is_mul = it.w != 0xffffffffu;
+    Fe part = fe_zero();
+    if (is_mul) {
+        const bool right = sub >= kEvalLanes / 2;
+        const u32 k = sub % (kEvalLanes / 2);
+        const u32 first = right ? it.z : it.y, cnt = right ? (it.w >> 16) : (it.w & 0xffffu);
+        const u32* col = right ? B.col : A.col;
+        const uint4* val = right ? B.val : A.val;
+#pragma unroll 1
+        for (u32 j = k; j < cnt; j += kEvalLanes / 2) {
+            const u32 c = gload(col + first + j);
+            const Fe v = fe_gload(val + 2 * (u64)(first + j));
+            const Fe p = fe_mul<F>(v, fe_gload(w + 2 * (u64)c));
+            part = (j == k) ? p : fe_add<F>(part, p);
+        }
+    }
+    // every lane of the wave takes part in the shuffles (groups of other kinds and groups past the end carry zeros)
+#pragma unroll 1
+    for (int off = 1; off < (int)kEvalLanes / 2; off <<= 1) {
+        Fe o;
+#pragma unroll
+        for (int i = 0; i < kLimbs; ++i) o.l[i] = (u32)__shfl_xor((int)part.l[i], off, kSlice);
+        part = fe_add<F>(part, o);
+    }
+    Fe other;
+#pragma unroll
+    for (int i = 0; i < kLimbs; ++i) other.l[i] = (u32)__shfl_xor((int)part.l[i], (int)kEvalLanes / 2, kSlice);
+    if (!live || sub != 0) return;
+    if (is_mul) {
+        fe_store(w + 2 * (u64)it.x, fe_mul<F>(part, other));
+        return;
+    }
+    eval_gate_generic<F>(G, A, B, w, G.items[t]);
 }
 
 // ---------------------------------------------------------------------------------------------
