@@ -187,6 +187,7 @@ struct acx_r1cs {
     u32 *ev_items = nullptr, *ev_row = nullptr, *ev_wire_ofs = nullptr, *ev_wires = nullptr;
     uint8_t* ev_kind = nullptr;
     uint4* ev_mul = nullptr;             // per plan item: the Mul gate's record (k_eval_level)
+    u32* ev_cols = nullptr;              // per plan item: kEvalLanes columns (k_eval_level_lanes)
     bool has_csc = false;
     uint4* d_w = nullptr;  // witness staging, m elements
     uint4* qh = nullptr;   // h(x) pipeline scratch, 5N elements (allocated on first use)
@@ -1068,6 +1069,7 @@ void free_r1cs_device(acx_r1cs* r) {
     if (r->perm) (void)hipFree(r->perm);
     if (r->long_rows) (void)hipFree(r->long_rows);
     if (r->ev_mul) { (void)hipFree(r->ev_mul); r->ev_mul = nullptr; }
+    if (r->ev_cols) { (void)hipFree(r->ev_cols); r->ev_cols = nullptr; }
     if (r->ev_items) (void)hipFree(r->ev_items);
     if (r->ev_row) (void)hipFree(r->ev_row);
     if (r->ev_wire_ofs) (void)hipFree(r->ev_wire_ofs);
@@ -1539,7 +1541,15 @@ static void ensure_eval_plan(acx_r1cs* r) {
         };
         if (up((void**)&r->ev_items, plan.items.data(), plan.items.size() * 4) && up((void**)&r->ev_row, row.data(), row.size() * 4) &&
             up((void**)&r->ev_wire_ofs, wofs.data(), wofs.size() * 4) && up((void**)&r->ev_wires, wflat.data(), wflat.size() * 4) &&
-            up((void**)&r->ev_kind, hc.kind.data(), hc.kind.size()) && up((void**)&r->ev_mul, mul.data(), mul.size() * 4)) {
+            up((void**)&r->ev_kind, hc.kind.data(), hc.kind.size()) && up((void**)&r->ev_mul, mul.data(), mul.size() * 4) &&
+            hipMalloc((void**)&r->ev_cols, plan.items.size() * kEvalLanes * 4 + 4) == hipSuccess) {
+            // level-ordered copy of the first four columns of each recorded Mul gate's A and B rows (k_eval_level_lanes)
+            const uint64_t lanes = (uint64_t)plan.items.size() * kEvalLanes;
+            if (lanes > 0) {
+                hipLaunchKernelGGL(k_eval_fill_cols, dim3((unsigned)((lanes + kBlock - 1) / kBlock)), dim3(kBlock), 0, cur_stream(ctx),
+                                   (const uint4*)r->ev_mul, (u32)plan.items.size(), (const u32*)r->M[0].idx, (const u32*)r->M[1].idx, r->ev_cols);
+                if (hipStreamSynchronize(cur_stream(ctx)) != hipSuccess) return;
+            }
             r->has_plan = true;
             r->plan_level_ofs = plan.level_ofs;
             r->plan_written = plan.written;
@@ -1722,7 +1732,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     for (size_t l = 0; l < n_levels; ++l) {
         const uint32_t lo = r->plan_level_ofs[l], cnt = r->plan_level_ofs[l + 1] - lo;
         if (cnt == 0) continue;
-        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo};
+        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo, r->ev_cols + (size_t)lo * kEvalLanes};
         if (cnt < lanes_below) {
             const uint32_t per_block = kBlock / kEvalLanes;
             DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level_lanes<F>), dim3((cnt + per_block - 1) / per_block), dim3(kBlock), 0, cur_stream(c),

@@ -782,6 +782,7 @@ struct EvalGates {
     const u32* wire_ofs;     // per gate: offset into wires (n_gates + 1)
     const u32* wires;        // flat wire indices: Mul {out}, Equal {i, m, out}, Split {inp, outs...}
     const uint4* mul;        // per item, level order: Mul gate {out wire, first A entry, first B entry, nA | nB << 16}, else .w = ~0
+    const u32* cols;         // per item, level order: kEvalLanes columns (entries 0-3 of the A row, 0-3 of the B row; k_eval_fill_cols)
 };
 
 // one gate of any kind on one lane (everything except the recorded Mul gates of a level)
@@ -831,13 +832,36 @@ __global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, Cs
 // takes EIGHT lanes: lanes 0-3 one entry each of its A row, lanes 4-7 of its B row (more entries: strided), every lane one
 // full Montgomery product, the partial sums folded by xor-shuffles, lane 0 multiplies and stores.  The chain is record ->
 // {column, value} -> witness, and ~650 instructions.  Other gate kinds run on lane 0 of their group as before.
+// The chain is record -> {column, value} -> witness; the level-ordered column copy (G.cols, 32 bytes per item) takes the
+// column out of it: a lane's column address depends on nothing but its index, so it is record -> value beside column -> witness.
 constexpr u32 kEvalLanes = 8;
+__global__ __launch_bounds__(kBlock) void k_eval_fill_cols(const uint4* __restrict__ mul, u32 count, const u32* __restrict__ col_a,
+                                                          const u32* __restrict__ col_b, u32* __restrict__ cols) {
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 t = i / kEvalLanes;
+    const u32 sub = (u32)(i % kEvalLanes);
+    if (t >= count) return;
+    const uint4 it = mul[t];
+    u32 c = 0;
+    if (it.w != 0xffffffffu) {
+        const bool right = sub >= kEvalLanes / 2;
+        const u32 k = sub % (kEvalLanes / 2);
+        const u32 first = right ? it.z : it.y, cnt = right ? (it.w >> 16) : (it.w & 0xffffu);
+        if (k < cnt) c = (right ? col_b : col_a)[first + k];
+    }
+    cols[i] = c;
+}
+
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_eval_level_lanes(EvalGates G, CsrDev A, CsrDev B, uint4* __restrict__ w) {
     const u32 t = (blockIdx.x * kBlock + threadIdx.x) / kEvalLanes, sub = threadIdx.x % kEvalLanes;
     const bool live = t < G.count;
     uint4 it = make_uint4(0u, 0u, 0u, 0xffffffffu);
-    if (live) it = gload(G.mul + t);
+    u32 my_col = 0;
+    if (live) {
+        it = gload(G.mul + t);
+        my_col = gload(G.cols + (u64)t * kEvalLanes + sub);
+    }
     const bool is_mul = it.w != 0xffffffffu;
     Fe part = fe_zero();
     if (is_mul) {
@@ -848,7 +872,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_level_lanes(EvalGates G, CsrDev
         const uint4* val = right ? B.val : A.val;
 #pragma unroll 1
         for (u32 j = k; j < cnt; j += kEvalLanes / 2) {
-            const u32 c = gload(col + first + j);
+            const u32 c = (j == k) ? my_col : gload(col + first + j);
             const Fe v = fe_gload(val + 2 * (u64)(first + j));
             const Fe p = fe_mul<F>(v, fe_gload(w + 2 * (u64)c));
             part = (j == k) ? p : fe_add<F>(part, p);

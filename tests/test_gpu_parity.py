@@ -883,29 +883,30 @@ def test_r1cs_2_24_rows_block_diagonal_properties(request, acx):
 
 
 # ------------------------------------------------------------------ bench.py multi-rank control flow on one GPU
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_device():
+def test_bench_ranks_on_one_device(world):
     """The N > 1 path of bench.py (per-rank systems, half-ring verdict all-reduce, MAX-over-ranks timing,
-    one JSON line from rank 0) with two ranks sharing cuda:0 over gloo: RCCL needs one GPU per rank, the
-    control flow does not."""
+    one JSON line from rank 0) with 2 and 8 ranks (the driver's SCALE run goes up to 8) sharing cuda:0 over gloo: RCCL needs one GPU per
+    rank, the control flow and the index arithmetic of the distributed transform do not."""
     _need_gpu()
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ACX_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(H.free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(H.free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "20",
            "--warmup", "3", "--copies", "4", "--no-cpu", "--no-ntt", "--dist-logn", "18"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == world and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["constraints_per_step_per_gpu"] == 4 << 16
-    assert abs(d["value"] - 2 * (4 << 16) * 20 / (d["ms_per_step"] * 20 * 1e-3)) / d["value"] < 1e-6
+    assert abs(d["value"] - world * (4 << 16) * 20 / (d["ms_per_step"] * 20 * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and "roofline" in d
     # the multi-rank line also times the distributed transform and the distributed h(x) (here 2^18, odd digits 9+9)
-    assert d["dist_ntt"]["parity_vs_oracle"] is True and d["dist_ntt"]["all_to_all_bytes_per_rank"] == (1 << 18) // 2 * 32 // 2
+    assert d["dist_ntt"]["parity_vs_oracle"] is True and d["dist_ntt"]["all_to_all_bytes_per_rank"] == (1 << 18) // world * 32 * (world - 1) // world
     assert d["dist_qap_h"]["accepts_valid_rejects_corrupt"] is True and d["dist_qap_h"]["us"] > 0
 
 
