@@ -156,6 +156,7 @@ struct DevMatrix {
     uint4* val = nullptr; // dev format
     u32* colid = nullptr; // CSC only: column of every entry
     uint64_t nnz = 0;
+    std::vector<uint32_t> h_ptr;   // CSC only: host copy of colptr (qap_columns_core sorts a batch into sparse and dense columns)
 };
 
 constexpr int kRowTiers = 4;
@@ -1194,6 +1195,8 @@ int ensure_csc(acx_r1cs* r) {
                                T.idx, T.colid, T.val);
         }
         HIP_TRY(hipGetLastError());
+        T.h_ptr.resize(r->m + 1);
+        HIP_TRY(hipMemcpyAsync(T.h_ptr.data(), T.ptr, (r->m + 1) * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));       // count / cursor go out of scope; other lanes may use the CSC from here on
     }
     r->has_csc = true;
@@ -1207,12 +1210,44 @@ int qap_columns_core(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t cnt,
     const uint64_t N = 1ull << r->log_n;
     const DevMatrix& T = r->T[matrix];
     if (cnt == 0) return ACX_OK;
-    HIP_TRY(hipMemsetAsync(d_out, 0, cnt * N * 32, cur_stream(c)));
-    if (T.nnz)
+    // Columns of at most kDirectMax entries (nearly every wire of a gate-list circuit) are interpolated directly
+    // (k_col_direct: k products per coefficient); the others -- inputs used by many gates, the constant wire -- form
+    // runs that take the batched inverse transform.  Many short runs: the whole batch takes the transform.
+    static const bool direct_ok = [] { const char* e = getenv("ACX_COLUMNS_DIRECT"); return !e || atoi(e) != 0; }();
+    std::vector<std::pair<uint64_t, uint64_t>> runs;      // dense runs [begin, end) inside the batch
+    uint64_t n_sparse = 0;
+    if (direct_ok && T.h_ptr.size() > wire_begin + cnt) {
+        const uint32_t* hp = T.h_ptr.data() + wire_begin;
+        for (uint64_t i = 0; i < cnt; ++i) {
+            if (hp[i + 1] - hp[i] <= kDirectMax) { ++n_sparse; continue; }
+            if (!runs.empty() && runs.back().second == i) runs.back().second = i + 1; else runs.emplace_back(i, i + 1);
+        }
+    }
+    if (n_sparse == 0 || runs.size() > 16) { runs.assign(1, {0, cnt}); n_sparse = 0; }
+    for (const auto& run : runs)
+        HIP_TRY(hipMemsetAsync(d_out + 2 * run.first * N, 0, (run.second - run.first) * N * 32, cur_stream(c)));
+    if (T.nnz && !runs.empty())       // entries of sparse columns land in memory the direct kernel overwrites afterwards
         hipLaunchKernelGGL(k_scatter_columns, dim3(grid_for(c, T.nnz / 4 + 1)), dim3(kBlock), 0, cur_stream(c), (const u32*)T.ptr, (const u32*)T.idx,
                            (const u32*)T.colid, (const uint4*)T.val, wire_begin, cnt, r->log_n, d_out);
-    ACX_TRY(ntt_dev_locked(c, d_out, r->log_n, cnt, 1, nullptr));
-    if (d_len) DISPATCH_FIELD(c, hipLaunchKernelGGL((k_poly_len<F>), dim3((unsigned)cnt), dim3(kBlock), 0, cur_stream(c), (const uint4*)d_out, r->log_n, d_len));
+    for (const auto& run : runs)
+        ACX_TRY(ntt_dev_locked(c, d_out + 2 * run.first * N, r->log_n, run.second - run.first, 1, nullptr));
+    if (n_sparse) {
+        ColDirect P{};
+        P.colptr = T.ptr; P.rowidx = T.idx; P.val = T.val; P.log_n = r->log_n;
+        P.steps = (u32)std::max<uint64_t>(1, std::min<uint64_t>(32, N / kBlock));
+        uint4 *lo = nullptr, *hi = nullptr;
+        ACX_TRY(get_low_table(c, r->log_n, 1, &lo));
+        if (r->log_n > 10) ACX_TRY(get_pow_table(c, r->log_n - 10, 1, &hi));
+        P.tw_lo = lo; P.tw_hi = hi;
+        P.inv_n = dev_arg(c->hf, c->hf.inv(c->hf.from_u64(N)));
+        const unsigned gx = (unsigned)std::max<uint64_t>(1, N / ((uint64_t)kBlock * P.steps));
+        for (uint64_t b = 0; b < cnt; b += 32768) {
+            const uint64_t nb = std::min<uint64_t>(32768, cnt - b);
+            P.wire_begin = wire_begin + b;
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_col_direct<F>), dim3(gx, (unsigned)nb), dim3(kBlock), 0, cur_stream(c), P, d_out + 2 * b * N));
+        }
+    }
+    if (d_len) DISPATCH_FIELD(c, hipLaunchKernelGGL((k_poly_len<F>), dim3((unsigned)cnt), dim3(kBlock), 0, cur_stream(c), (const uint4*)d_out, r->log_n, d_len, (const u32*)T.ptr + wire_begin));
     HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

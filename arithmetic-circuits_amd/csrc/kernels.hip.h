@@ -962,12 +962,79 @@ __global__ __launch_bounds__(kBlock) void k_scatter_columns(const u32* __restric
     }
 }
 
+// `FFT.interpolate` of a SPARSE column without a transform.  A QAP column is the interpolant of a wire's few appearances
+// (an intermediate wire of a Mul-gate circuit has one entry in C and one or two in A / B): with k nonzero values v_t at roots
+// omega^(i_t) the coefficients are c_j = (1/N) sum_t v_t omega^(-i_t j) -- k geometric progressions -- i.e. k Montgomery
+// products per coefficient against the ~10 of the radix-2 transform, no zero fill and no scatter.  Columns with more than
+// kDirectMax entries keep the batched inverse NTT (the host splits a batch into dense runs and the rest).
+// blockIdx.y = column of the batch; a block produces kBlock * L consecutive coefficients, lane l the coefficients
+// base + l + kBlock * s (every store of the block is one contiguous 8 KiB run), stepping each progression by omega^(-256 i_t).
+constexpr u32 kDirectMax = 4;
+struct ColDirect {
+    const u32* colptr;
+    const u32* rowidx;
+    const uint4* val;
+    u64 wire_begin;
+    u32 log_n;
+    u32 steps;              // L
+    const uint4* tw_lo;     // omega_N^-j, j < min(N, 1024)
+    const uint4* tw_hi;     // omega_N^-(1024 j), j < N / 1024 (null for N <= 1024)
+    FeArg inv_n;            // 1/N (Montgomery)
+};
+
+template <class F>
+__device__ __forceinline__ Fe omega_inv_pow(const ColDirect& P, u64 e) {     // omega_N^-e, e < N
+    if (P.tw_hi == nullptr) return fe_gload(P.tw_lo + 2 * e);
+    return fe_mul<F>(fe_gload(P.tw_lo + 2 * (e & 1023u)), fe_gload(P.tw_hi + 2 * (e >> 10)));
+}
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_col_direct(ColDirect P, uint4* __restrict__ out) {
+    const u64 wire = P.wire_begin + blockIdx.y;
+    const u32 e0 = P.colptr[wire], k = P.colptr[wire + 1] - e0;
+    if (k > kDirectMax) return;                                   // a dense column: the transform's
+    const u64 N = 1ull << P.log_n, mask = N - 1;
+    const u64 j0 = (u64)blockIdx.x * kBlock * P.steps + threadIdx.x;
+    if (j0 >= N) return;                                          // N < kBlock
+    uint4* dst = out + 2 * (((u64)blockIdx.y << P.log_n) + j0);
+    Fe cur[kDirectMax], ratio[kDirectMax];
+    const Fe inv_n = fe_from_arg(P.inv_n);
+#pragma unroll
+    for (u32 t = 0; t < kDirectMax; ++t) {
+        if (t < k) {                                              // k is uniform over the block
+            const u64 i = P.rowidx[e0 + t];
+            const Fe v = fe_mul<F>(fe_gload(P.val + 2 * (u64)(e0 + t)), inv_n);
+            cur[t] = fe_mul<F>(v, omega_inv_pow<F>(P, (i * j0) & mask));
+            ratio[t] = omega_inv_pow<F>(P, (i * kBlock) & mask);
+        }
+    }
+#pragma unroll 1
+    for (u32 s = 0; s < P.steps; ++s) {
+        Fe sum = fe_zero();
+#pragma unroll
+        for (u32 t = 0; t < kDirectMax; ++t) {
+            if (t < k) {
+                sum = (t == 0) ? cur[0] : fe_add<F>(sum, cur[t]);
+                if (s + 1 < P.steps) cur[t] = fe_mul<F>(cur[t], ratio[t]);
+            }
+        }
+        fe_store(dst + 2 * (u64)s * kBlock, sum);
+    }
+}
+
 // len[w] = 1 + index of the last nonzero coefficient of polynomial w (0 for the zero polynomial): poly's `toPoly`
 // stripping, computed where the data is.  One workgroup per polynomial, scanning down from the top.
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_poly_len(const uint4* __restrict__ data, u32 log_n, unsigned long long* __restrict__ len) {
+__global__ __launch_bounds__(kBlock) void k_poly_len(const uint4* __restrict__ data, u32 log_n, unsigned long long* __restrict__ len,
+                                                    const u32* __restrict__ colptr) {
     const u64 N = 1ull << log_n;
     const uint4* p = data + 2 * ((u64)blockIdx.x << log_n);
+    // a column without entries is the zero polynomial: no scan (one workgroup walking 2^20 zeros takes milliseconds, and
+    // 37 % of the A / B columns of a k = 2 Mul-gate circuit are empty); colptr points at the batch's first column
+    if (colptr != nullptr && colptr[blockIdx.x] == colptr[blockIdx.x + 1]) {
+        if (threadIdx.x == 0) len[blockIdx.x] = 0;
+        return;
+    }
     __shared__ u32 best;
     if (threadIdx.x == 0) best = 0;
     __syncthreads();

@@ -117,8 +117,12 @@ def bench_cols(ctx, stream, log_n, wires=64):
     out = torch.empty((wires * n, 4), dtype=torch.int64, device="cuda")
     lens = torch.zeros(wires, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
-    us = time_stream(stream, lambda: r.qap_columns_dev(0, 1, wires, out.data_ptr(), lens.data_ptr()), 5)
-    print(f"qap_columns_dev N=2^{log_n}, {wires} wires per call: {us:9.1f} us = {us / wires:7.1f} us per column, {wires / us * 1e6:.0f} columns/s")
+    # wires 1 .. 1024 are the circuit's inputs (hundreds of appearances each: batched inverse NTT); the intermediate wires
+    # behind them appear once in C and once or twice in A / B (direct interpolation, k_col_direct)
+    mid0 = 1 + N_IN + n // 2
+    for what, w0, mat in (("input wires, A", 1, 0), ("intermediate wires, A", mid0, 0), ("intermediate wires, C", mid0, 2)):
+        us = time_stream(stream, lambda: r.qap_columns_dev(mat, w0, wires, out.data_ptr(), lens.data_ptr()), 5)
+        print(f"qap_columns_dev N=2^{log_n}, {wires} {what} per call: {us:9.1f} us = {us / wires:7.1f} us per column, {wires / us * 1e6:.0f} columns/s")
     total = 4 * wires
     r.qap_columns(0, 1, wires)
     t0 = time.perf_counter()
