@@ -90,6 +90,7 @@ SYMBOLS = {
     "acx_qap_h_dev": (_I, [_P, _P, _P, _P, _P]),
     "acx_qap_columns_dev": (_I, [_P, _I, _U64, _U64, _P, _P]),
     "acx_qap_pointwise_dev": (_I, [_P, _U32, _U64, _P, _P, _P, _P, _P]),
+    "acx_qap_sub_o_dev": (_I, [_P, _U32, _U64, _P, _P, _P]),
     "acx_ntt_dist_step_dev": (_I, [_P, _U32, _U32, _U32, _U32, _I, _I, _P, _P, _P]),
     "acx_batch_create": (_I, [_P, _U64, _P, _P, _P, _U64, C.POINTER(_P)]),
     "acx_batch_verify_dev": (_I, [_P]),

@@ -1819,8 +1819,8 @@ int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out) {
     return download_elements(c, res, r->n, out, res);
 }
 
-// verificationWitnessZk on device-resident data (caller holds ctx->mu): residual dots -> 3 iNTT -> 3 coset NTT ->
-// pointwise -> coset iNTT (+ the zero-knowledge terms).  d_h receives N+1 dev elements, not stripped.
+// verificationWitnessZk on device-resident data (caller holds ctx->mu): residual dots -> 3 iNTT -> 2 coset NTT (L, R) ->
+// pointwise -> coset iNTT -> minus O0 / z in coefficient form (+ the zero-knowledge terms).  d_h receives N+1 dev elements, not stripped.
 static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4* d_h, unsigned long long* d_result,
                             uint4* d /* 5N elements of scratch */) {
     acx_ctx* c = r->ctx;
@@ -1834,30 +1834,38 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
     const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
     // coset: shift = multiplicative generator g (g^N != 1)
     const H256 g = hf.generator();
-    // evaluations on <omega> -> coefficients of L0, R0, O0 -> evaluations on g<omega>.  Without the zero-knowledge terms
-    // nobody needs the plain coefficients, so the factor g^i rides on the inverse transform's closing multiplication.
-    int fused = zk ? ACX_ERR_UNSUPPORTED : ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr, &g);
+    // evaluations on <omega> -> coefficients of L0, R0, O0; L0 and R0 -> evaluations on g<omega>.  O0 stays in coefficient
+    // form: h = icoset((L R - O)/z) = icoset(L R / z) - O0 / z by linearity (icoset after coset is the identity), which
+    // drops one of the seven transforms.  Without the zero-knowledge terms nobody needs the plain coefficients of L0 and
+    // R0, so their factor g^i rides on the inverse transform's closing multiplication.
+    uint4* O0 = d + 4 * N;
+    int fused = zk ? ACX_ERR_UNSUPPORTED : ntt_dev_locked(c, d, r->log_n, 2, 1, nullptr, &g);
     if (fused == ACX_OK) {
-        ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, nullptr));
+        ACX_TRY(ntt_dev_locked(c, O0, r->log_n, 1, 1, nullptr));
+        ACX_TRY(ntt_dev_locked(c, d, r->log_n, 2, 0, nullptr));
     } else {
         ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr));
         if (zk) HIP_TRY(hipMemcpyAsync(keep, d, 2 * N * 32, hipMemcpyDeviceToDevice, cur_stream(c)));
-        ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 0, &g));
+        ACX_TRY(ntt_dev_locked(c, d, r->log_n, 2, 0, &g));
     }
     const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
     DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d,
-                                         (const uint4*)(d + 2 * N), (const uint4*)(d + 4 * N), d_h, N, dev_arg(hf, zinv), zk ? 0u : 1u));
+                                         (const uint4*)(d + 2 * N), (const uint4*)nullptr, d_h, N, dev_arg(hf, zinv), zk ? 0u : 1u));
     ACX_TRY(ntt_dev_locked(c, d_h, r->log_n, 1, 1, &g));
+    const H256 mzinv = hf.sub(hf.zero(), zinv);
     if (zk) {
         // (L0+d1 T)(R0+d2 T) - (O0+d3 T) = T * (h0 + d1 R0 + d2 L0 + d1 d2 T - d3),  T = x^N - 1
         const uint4* L0 = keep;
         const uint4* R0 = L0 + 2 * N;
         const H256 d12 = hf.mul(dl[0], dl[1]);
         DISPATCH_FIELD(c, {
-            hipLaunchKernelGGL((k_axpy2<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, R0, L0, N,
-                               dev_arg(hf, dl[0]), dev_arg(hf, dl[1]));
+            hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, R0, L0, (const uint4*)O0, N,
+                               dev_arg(hf, dl[0]), dev_arg(hf, dl[1]), dev_arg(hf, mzinv));
             hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, cur_stream(c), d_h, N, dev_arg(hf, hf.add(d12, dl[2])), dev_arg(hf, d12));
         });
+    } else {
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, (const uint4*)nullptr,
+                                             (const uint4*)nullptr, (const uint4*)O0, N, dev_arg(hf, mzinv), dev_arg(hf, mzinv), dev_arg(hf, mzinv)));
     }
     HIP_TRY(hipGetLastError());
     return ACX_OK;
@@ -2004,7 +2012,7 @@ int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset,
 
 int acx_qap_pointwise_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_fr* shift, const void* d_a, const void* d_b,
                           const void* d_c, void* d_out) {
-    if (!c || !shift || !d_a || !d_b || !d_c || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (!c || !shift || !d_a || !d_b || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");      // d_c may be NULL
     if (count == 0) return ACX_OK;
     const HostField& hf = c->hf;
     H256 g;
@@ -2015,6 +2023,23 @@ int acx_qap_pointwise_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_
     HIP_TRY(hipSetDevice(c->device));
     DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d_a,
                                          (const uint4*)d_b, (const uint4*)d_c, (uint4*)d_out, count, dev_arg(hf, hf.inv(z)), 0u));
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
+int acx_qap_sub_o_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_fr* shift, void* d_h, const void* d_o) {
+    if (!c || !shift || !d_h || !d_o) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (count == 0) return ACX_OK;
+    const HostField& hf = c->hf;
+    H256 g;
+    ACX_TRY(read_h256(shift, hf, g));
+    const H256 z = hf.sub(hf.pow_u64(g, 1ull << log_n), hf.one());
+    if (z.is_zero()) return fail(ACX_ERR_INVALID_ARG, "shift^N = 1: the coset meets the evaluation domain");
+    const H256 mzinv = hf.sub(hf.zero(), hf.inv(z));
+    CtxLock lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, cur_stream(c), (uint4*)d_h, (const uint4*)nullptr,
+                                         (const uint4*)nullptr, (const uint4*)d_o, count, dev_arg(hf, mzinv), dev_arg(hf, mzinv), dev_arg(hf, mzinv)));
     HIP_TRY(hipGetLastError());
     return ACX_OK;
 }

@@ -597,7 +597,10 @@ __global__ __launch_bounds__(kBlock) void k_ntt_tile(NttPass P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5: h on the coset: out[i] = (a[i]*b[i] - c[i]) * zinv   (src/QAP.hs:325-327 in evaluation form)
+// K5: h on the coset: out[i] = (a[i]*b[i] - c[i]) * zinv   (src/QAP.hs:325-327 in evaluation form).  c == nullptr:
+// out[i] = a[i]*b[i]*zinv -- the pipeline then subtracts zinv * O(x) in the COEFFICIENT domain after the inverse coset
+// transform (the transform is linear and coset-NTT followed by inverse-coset-NTT is the identity on O's coefficients, so
+// O never needs its coset evaluations: six transforms per h(x) instead of seven).
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_pointwise_h(const uint4* __restrict__ a, const uint4* __restrict__ b,
                                                        const uint4* __restrict__ c, uint4* __restrict__ out, u64 n,
@@ -606,7 +609,8 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_h(const uint4* __restrict_
     if (zero_top && blockIdx.x == 0 && threadIdx.x == 0) fe_store(out + 2 * n, fe_zero());   // h has N+1 coefficients; the
                                                                                              // transform that follows leaves it alone
     for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
-        const Fe t = fe_sub<F>(fe_mul<F>(fe_load(a + 2 * i), fe_load(b + 2 * i)), fe_load(c + 2 * i));
+        Fe t = fe_mul<F>(fe_load(a + 2 * i), fe_load(b + 2 * i));
+        if (c != nullptr) t = fe_sub<F>(t, fe_load(c + 2 * i));
         fe_store(out + 2 * i, fe_mul<F>(t, zinv));
     }
 }
@@ -620,14 +624,17 @@ __global__ void k_h_fix(uint4* __restrict__ h, u64 top_index, FeArg sub0, FeArg 
     }
 }
 
-// h += d1 * R0 + d2 * L0 elementwise (zero-knowledge shift, src/QAP.hs:315-323)
+// h += ax * x + ay * y + az * z elementwise; null vectors are skipped.  The zero-knowledge shift d1 * R0 + d2 * L0
+// (src/QAP.hs:315-323) and the coefficient-domain subtraction of zinv * O0 (k_pointwise_h) in one pass.
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_axpy2(uint4* __restrict__ h, const uint4* __restrict__ x,
-                                                 const uint4* __restrict__ y, u64 n, FeArg ax_arg, FeArg ay_arg) {
-    const Fe ax = fe_from_arg(ax_arg), ay = fe_from_arg(ay_arg);
+__global__ __launch_bounds__(kBlock) void k_axpy3(uint4* __restrict__ h, const uint4* __restrict__ x, const uint4* __restrict__ y,
+                                                 const uint4* __restrict__ z, u64 n, FeArg ax_arg, FeArg ay_arg, FeArg az_arg) {
+    const Fe ax = fe_from_arg(ax_arg), ay = fe_from_arg(ay_arg), az = fe_from_arg(az_arg);
     for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
-        Fe t = fe_add<F>(fe_load(h + 2 * i), fe_mul<F>(ax, fe_load(x + 2 * i)));
-        t = fe_add<F>(t, fe_mul<F>(ay, fe_load(y + 2 * i)));
+        Fe t = fe_load(h + 2 * i);
+        if (x != nullptr) t = fe_add<F>(t, fe_mul<F>(ax, fe_load(x + 2 * i)));
+        if (y != nullptr) t = fe_add<F>(t, fe_mul<F>(ay, fe_load(y + 2 * i)));
+        if (z != nullptr) t = fe_add<F>(t, fe_mul<F>(az, fe_load(z + 2 * i)));
         fe_store(h + 2 * i, t);
     }
 }

@@ -103,9 +103,15 @@ class Context:
         check(self.lib.acx_ntt_dev(self._h, log_n, batch, int(inverse), _ptr(sh), d_data))
 
 
-    def qap_pointwise_dev(self, d_a: int, d_b: int, d_c: int, d_out: int, count: int, log_n: int, shift: int) -> None:
+    def qap_pointwise_dev(self, d_a: int, d_b: int, d_c: Optional[int], d_out: int, count: int, log_n: int, shift: int) -> None:
+        """out = (a*b - c) / (shift^N - 1); d_c = None: out = a*b / (shift^N - 1)."""
         sh = ints_to_fr([shift])
         check(self.lib.acx_qap_pointwise_dev(self._h, log_n, count, _ptr(sh), d_a, d_b, d_c, d_out))
+
+    def qap_sub_o_dev(self, d_h: int, d_o: int, count: int, log_n: int, shift: int) -> None:
+        """h -= o / (shift^N - 1): O(x) enters the quotient in coefficient form (include/acx.h)."""
+        sh = ints_to_fr([shift])
+        check(self.lib.acx_qap_sub_o_dev(self._h, log_n, count, _ptr(sh), d_h, d_o))
 
     def ntt_dist_step_dev(self, d_in: int, d_out: int, log_n: int, log_r: int, world: int, rank: int, inverse: bool, step: int,
                           shift: Optional[int] = None) -> None:

@@ -14,8 +14,8 @@ below follows from the maths of the path:
     that launch and the w_N^(i2*k1) twiddle is its closing multiplication.
   * h(x) (`verificationWitnessZk`, src/QAP.hs:309-327) over all GPUs: rows are owned
     block-cyclically (rank g: rows r with (r mod R) in block g) so that the residual kernel writes
-    <A_i,w>, <B_i,w>, <C_i,w> straight into the layout the first inverse transform reads; seven
-    distributed transforms = seven all-to-alls, nothing else moves.
+    <A_i,w>, <B_i,w>, <C_i,w> straight into the layout the first inverse transform reads; six
+    distributed transforms = six all-to-alls, nothing else moves.
 
 The collectives live here, above the C ABI; libacx only ever sees one GPU (a C host does the same
 with rcclCommInitRank / ncclAllToAll: INTEGRATION.md).  `LocalOps` is the seam: the product uses
@@ -230,8 +230,12 @@ class LocalOps:
                   inverse: bool, step: int, shift: Optional[int]) -> None:
         raise NotImplementedError
 
-    def pointwise_h(self, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, out: torch.Tensor, log_n: int, shift: int) -> None:
-        """out = (a*b - c) / (shift^N - 1) elementwise (src/QAP.hs:325-327 on the coset)."""
+    def pointwise_h(self, a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], out: torch.Tensor, log_n: int, shift: int) -> None:
+        """out = (a*b - c) / (shift^N - 1) elementwise (src/QAP.hs:325-327 on the coset); c = None: a*b / (shift^N - 1)."""
+        raise NotImplementedError
+
+    def sub_o(self, h: torch.Tensor, o: torch.Tensor, log_n: int, shift: int) -> None:
+        """h -= o / (shift^N - 1) elementwise: O(x) enters the quotient in coefficient form."""
         raise NotImplementedError
 
 
@@ -257,7 +261,11 @@ class HipOps(LocalOps):
         self._fenced(lambda: self.ctx.ntt_dist_step_dev(src.data_ptr(), dst.data_ptr(), log_n, log_r, world, rank, inverse, step, shift))
 
     def pointwise_h(self, a, b, c, out, log_n, shift):
-        self._fenced(lambda: self.ctx.qap_pointwise_dev(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), a.shape[0], log_n, shift))
+        self._fenced(lambda: self.ctx.qap_pointwise_dev(a.data_ptr(), b.data_ptr(), c.data_ptr() if c is not None else None,
+                                                        out.data_ptr(), a.shape[0], log_n, shift))
+
+    def sub_o(self, h, o, log_n, shift):
+        self._fenced(lambda: self.ctx.qap_sub_o_dev(h.data_ptr(), o.data_ptr(), h.shape[0], log_n, shift))
 
 
 class DistributedNTT:
@@ -269,7 +277,7 @@ class DistributedNTT:
     Local layouts (include/acx.h, acx_ntt_dist_step_dev), N/W elements each:
         COLS [i2l][i1]   x[i1*C + g*C/W + i2l]          ROWS [kl][k2]   X[(g*R/W + kl) + k2*R]
     forward(): COLS -> ROWS, inverse(): ROWS -> COLS.  One all-to-all each way (N*32*(W-1)/W bytes over xGMI,
-    every link busy); a pipeline of transforms (the 7 NTTs of h(x)) alternates the two layouts, so nothing is
+    every link busy); a pipeline of transforms (the 6 NTTs of h(x)) alternates the two layouts, so nothing is
     ever re-ordered in between."""
 
     def __init__(self, log_n: int, ops: LocalOps, group=None, log_r: Optional[int] = None, force_collective: bool = False):
@@ -389,9 +397,11 @@ class DistributedQapH:
     """`verificationWitness` (src/QAP.hs:292-327, delta = 0) over all GPUs: h = (L*R - O) / (x^N - 1).
 
     Rows are owned block-cyclically (ShardedR1CS.from_cyclic), so the residual kernel's <A_i,w>, <B_i,w>, <C_i,w>
-    ARE the ROWS layout of three evaluation vectors.  Then 3 inverse transforms (-> coefficients, COLS), 3 forward
-    coset transforms (-> ROWS), the pointwise quotient, 1 inverse coset transform: h's coefficients in COLS layout
-    (rank g holds h[i1*C + g*C/W + i2l]).  Seven all-to-alls, one verdict all-reduce."""
+    ARE the ROWS layout of three evaluation vectors.  Then 3 inverse transforms (-> coefficients, COLS), 2 forward
+    coset transforms (L and R -> ROWS), the pointwise product / z, 1 inverse coset transform and, in coefficient form,
+    minus O / z: h's coefficients in COLS layout (rank g holds h[i1*C + g*C/W + i2l]).  O(x) never needs its coset
+    evaluations -- the transforms are linear and icoset(coset(O)) = O -- so there are six all-to-alls, not seven, and
+    one verdict all-reduce."""
 
     def __init__(self, sharded: ShardedR1CS, ntt: DistributedNTT, generator: int):
         assert sharded.rows.shape[0] == ntt.local
@@ -410,17 +420,19 @@ class DistributedQapH:
         part = lambda t, k: t[k * L:(k + 1) * L]
         # Software pipeline over the three vectors: the exchange of vector k runs (on RCCL's stream) under the local
         # steps of vector k+1, and a vector's forward transform starts as soon as its inverse one is complete -- of
-        # the seven all-to-alls only the last one has no local work to hide behind.  Without an overlapping backend
+        # the six all-to-alls only the last one has no local work to hide behind.  Without an overlapping backend
         # (one rank, gloo) begin() completes the exchange itself and this is the plain sequence.
         with nt.stream_context():
             inv = [nt.begin(part(dots, k), True, None, slot=k) for k in range(3)]
             fwd = []
             for k in range(3):
                 nt.finish(inv[k], out=part(tmp, k))
-                fwd.append(nt.begin(part(tmp, k), False, self.g, slot=k))
-            for k in range(3):
+                if k < 2:
+                    fwd.append(nt.begin(part(tmp, k), False, self.g, slot=k))
+            for k in range(2):
                 nt.finish(fwd[k], out=part(dots, k))
-            nt.ops.pointwise_h(dots[:L], dots[L:2 * L], dots[2 * L:], tmp[:L], nt.log_n, self.g)
+            nt.ops.pointwise_h(dots[:L], dots[L:2 * L], None, tmp[:L], nt.log_n, self.g)
             h = nt.finish(nt.begin(tmp[:L], True, self.g, slot=0), out=tmp[L:2 * L])
+            nt.ops.sub_o(h, part(tmp, 2), nt.log_n, self.g)            # O's coefficients are in COLS ownership, like h
         ok, _, _ = self.sharded._reduce(verdict, first, False)
         return h, ok

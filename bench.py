@@ -157,7 +157,8 @@ def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=40, prewarm=0.25, batch
 def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
     """configs[2]'s third C3 metric: the h(x) pipeline of verificationWitness (src/QAP.hs:309-327) on a
     2^20-constraint mulgraph system, device resident (witness in, N+1 coefficients out): residual dots,
-    3 iNTT, 3 coset NTT, pointwise, coset iNTT.  Parity gate: every coefficient against the C oracle."""
+    3 iNTT, 2 coset NTT (L, R), pointwise, coset iNTT, minus O / z in coefficient form -- six transforms.
+    Parity gate: every coefficient against the C oracle (which runs the textbook seven)."""
     from oracle.c_oracle import COracle
     orc = COracle(field)
     n = 1 << log_n
@@ -175,9 +176,9 @@ def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
     parity = bool(ok and int(res[0]) == 0 and np.array_equal(got, want))
     us = _timed(stream, lambda: r.qap_h_dev(dw.data_ptr(), dh.data_ptr(), res.data_ptr()), reps, prewarm)
     b_r1cs, nnz, _ = algorithmic_bytes(mats, n)
-    alg = 7 * 128 * n + (b_r1cs + 3 * 32 * n) + 5 * 32 * n     # 7 NTTs + residual-style dots (written) + pointwise
-    ops = 7 * (1.5 * n * log_n) + 4 * n + nnz + n               # butterflies, scalings, dot-product MACs, pointwise
-    return {"workload": f"verificationWitness h(x), 2^{log_n}-constraint mulgraph ({field} Fr), device resident: residual dots + 7 NTTs + pointwise",
+    alg = 7 * 128 * n + (b_r1cs + 3 * 32 * n) + 5 * 32 * n     # SURVEY.md 8(d)'s definition of the job: 7 NTTs + residual-style dots (written) + pointwise
+    ops = 6 * (1.5 * n * log_n) + 4 * n + nnz + 2 * n           # butterflies of the SIX transforms actually run, scalings, dot-product MACs, pointwise + O / z
+    return {"workload": f"verificationWitness h(x), 2^{log_n}-constraint mulgraph ({field} Fr), device resident: residual dots + 6 NTTs (O stays in coefficient form) + pointwise", "transforms": 6,
             "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6, "roofline": _hbm(alg, us)}
 
 
@@ -219,7 +220,7 @@ def bench_small_coeff(ctx, stream, field="bn254", copies=32, log_n=16, reps=50, 
 def bench_distributed(ctx, a, world, rank, dist):
     """configs[3] beside the headline (N > 1, or --force-dist on one GPU): the distributed four-step NTT at
     N = 2^24 (one all-to-all per transform) and the distributed h(x) pipeline on a 2^24-constraint block system
-    (256 x 2^16 mulgraph blocks, rows marshalled per rank in block-cyclic ownership; 7 all-to-alls + 1 all-reduce).
+    (256 x 2^16 mulgraph blocks, rows marshalled per rank in block-cyclic ownership; 6 all-to-alls + 1 all-reduce: O(x) stays in coefficient form).
     Times are max over ranks.  Parity gates: transform round trip at 2^24 plus a full oracle comparison of the same
     code path at 2^16; the pipeline must accept the satisfying witness and reject a corrupted one."""
     par = importlib.import_module("arithmetic-circuits_amd.parallel")
@@ -292,7 +293,7 @@ def bench_distributed(ctx, a, world, rank, dist):
     _, ok_bad = qh.run(to_dev(ctx, wb))
     sec = wall(lambda: qh.run(dw), 3)
     out["dist_qap_h"] = {"workload": f"distributed verificationWitness h(x): {blocks} x 2^16-constraint mulgraph blocks = 2^{ln} constraints over "
-                                     f"{world} rank(s), block-cyclic rows, 7 all-to-alls (6 of them issued asynchronously under the next vector's local steps) + 1 all-reduce",
+                                     f"{world} rank(s), block-cyclic rows, 6 all-to-alls (5 of them issued asynchronously under the next vector's local steps) + 1 all-reduce",
                          "exchange_overlapped": bool(d.overlapped(dw)),
                          "accepts_valid_rejects_corrupt": bool(ok and not ok_bad), "us": sec * 1e6,
                          "constraints_per_s": bs.n / sec}

@@ -297,9 +297,16 @@ int acx_ntt_dist_step_dev(acx_ctx* ctx, uint32_t log_n, uint32_t log_r, uint32_t
 
 /* The pointwise step of h(x) on a coset (src/QAP.hs:325-327 in evaluation form): out[i] = (a[i]*b[i] - c[i]) /
  * (shift^N - 1), N = 2^log_n, on `count` dev elements (any slice of the evaluation vectors: the operation is
- * layout agnostic, which is what lets the distributed pipeline keep its block layouts). */
+ * layout agnostic, which is what lets the distributed pipeline keep its block layouts).
+ * d_c = NULL: out[i] = a[i]*b[i] / (shift^N - 1).  The pipelines use this form: the transforms are linear and a coset
+ * transform followed by its inverse is the identity, so O(x) never needs its coset evaluations --
+ * h = icoset(L*R / z) - O / z with O in COEFFICIENT form (acx_qap_sub_o_dev), six transforms per h(x) instead of seven. */
 int acx_qap_pointwise_dev(acx_ctx* ctx, uint32_t log_n, uint64_t count, const acx_fr* shift, const void* d_a,
                           const void* d_b, const void* d_c, void* d_out);
+
+/* d_h[i] -= d_o[i] / (shift^N - 1) on `count` dev elements: the coefficient-domain half of the quotient above
+ * (h and O's coefficients in the same layout; in the distributed pipeline both are in COLS ownership). */
+int acx_qap_sub_o_dev(acx_ctx* ctx, uint32_t log_n, uint64_t count, const acx_fr* shift, void* d_h, const void* d_o);
 
 /* Batched verification: `count` independent (constraint system, witness) pairs checked by ONE
  * kernel launch -- the shape of the reference's property tests, `all (verifyAssignment qap .

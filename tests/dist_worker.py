@@ -80,7 +80,13 @@ class OracleOps(par.LocalOps):
     def pointwise_h(self, a, b, c, out, log_n, shift):
         p = self.orc.p
         zinv = pow(pow(shift, 1 << log_n, p) - 1, -1, p)
-        out.copy_(_tensor([(x * y - z) * zinv % p for x, y, z in zip(_ints(a), _ints(b), _ints(c))]))
+        cs = _ints(c) if c is not None else [0] * a.shape[0]
+        out.copy_(_tensor([(x * y - z) * zinv % p for x, y, z in zip(_ints(a), _ints(b), cs)]))
+
+    def sub_o(self, h, o, log_n, shift):
+        p = self.orc.p
+        zinv = pow(pow(shift, 1 << log_n, p) - 1, -1, p)
+        h.copy_(_tensor([(x - y * zinv) % p for x, y in zip(_ints(h), _ints(o))]))
 
 
 def main():
