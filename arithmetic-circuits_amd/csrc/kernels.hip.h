@@ -318,6 +318,22 @@ struct SellSystem {
     ResidualOut out;
 };
 
+// The system descriptor of a launch BY VALUE, in scalar registers: `systems` (batched launch) is read through the constant
+// address space -- uniform s_load instructions -- or the kernel argument `one` is taken.  Binding a reference to
+// `systems != nullptr ? systems[blockIdx.y] : one` instead makes every field access a flat load into vector registers, with
+// the pointers living in VGPRs and every wait on them counted against both vmcnt and lgkmcnt: 138 against 117 us on 2^21 rows.
+typedef __attribute__((address_space(4))) const unsigned long long c_u64;
+static_assert(sizeof(SellSystem) % 8 == 0, "descriptor is copied in 8-byte words");
+__device__ __forceinline__ SellSystem sell_system_of_launch(const SellSystem* systems, const SellSystem& one) {
+    if (systems == nullptr) return one;
+    SellSystem S;
+    c_u64* src = (c_u64*)(unsigned long long)(systems + blockIdx.y);
+    unsigned long long* dst = (unsigned long long*)&S;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(SellSystem) / 8; ++i) dst[i] = src[i];
+    return S;
+}
+
 // K2: r_i = <A_i,w> * <B_i,w> - <C_i,w> for every row (verifyAssignment, src/QAP.hs:276-327, in the
 // evaluation domain).  One wave per slice, one lane per row; blockIdx.y selects the system of a
 // batched launch.  XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order),
@@ -330,7 +346,7 @@ struct SellSystem {
 // SPEC = 2: anything else; the form of each matrix is a run-time flag of its system.
 template <class F, int SPEC = 0>
 __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
-    const SellSystem& S = systems != nullptr ? systems[blockIdx.y] : one;   // batched : single
+    const SellSystem S = sell_system_of_launch(systems, one);               // batched : single
     const u32 tiles = (S.n_slices + 3) / 4;
     const u32 per_xcd = (tiles + 7) / 8;
     const u32 tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -357,6 +373,45 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
         for (int i = 0; i < kLimbs; ++i) a.l[i] = park[i][threadIdx.x];
     }
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
+}
+
+// K2, wave-specialised form: a slice takes THREE waves, one per matrix -- wave 0 forms <A,w>, wave 1 <B,w>, wave 2 <C,w>
+// (for the unit C of every gate the reference emits that is gathers and additions only); waves 1 and 2 park their dot
+// products in LDS and leave, wave 0 does the closing a*b - c test.  Against one wave walking A, B, C in turn: a slice's three
+// streams are in flight together, multiplier-bound waves (A, B) and a memory-bound one (C) share every SIMD, nothing waits
+// in LDS while another dot product is formed (75 VGPRs = 6 waves per SIMD instead of 90 = 5), and a launch too small to
+// fill the chip (configs[1] taken literally: 2^16 rows = 1024 slices) costs one dot product's latency, not three.
+// Measured (tools/split_sweep.py, one system; both kernels with the descriptor in scalar registers): 2^16 rows 6.9 -> 5.8 us,
+// 2^21 119.4 -> 116.3 us; the bench's 32 x 2^16 rows 120.4 -> 116.8 us.  Forcing 7 waves per SIMD (72 VGPRs, 24 bytes of
+// scratch) costs 25 % (145.9 us).
+// blockIdx.y selects the system of a batched launch; XCD-contiguous slice order as in k_r1cs_sell.  SPEC as there.
+template <class F, int SPEC = 0>
+__global__ __launch_bounds__(3 * kSlice) void k_r1cs_sell_split(const SellSystem* __restrict__ systems, SellSystem one) {
+    const SellSystem S = sell_system_of_launch(systems, one);               // batched : single
+    const u32 per_xcd = (S.n_slices + 7) / 8;
+    const u32 slice = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (blockIdx.x >= 8 * per_xcd || slice >= S.n_slices) return;          // uniform over the workgroup
+    const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kSlice), lane = threadIdx.x % kSlice;
+    constexpr bool kMixed = SPEC == 2;
+    __shared__ u32 park[2][kLimbs][kSlice];
+    Fe d;
+    if (wv == 0) d = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
+    else if (wv == 1) d = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
+    else d = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
+             : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
+    // Wave 0 closes.  (Closing on the C wave, which is done first, is SLOWER -- 133 against 117 us on 2^21 rows: it would sit
+    // in the barrier holding its wave slot until the two multiplier waves arrive, whereas here waves 1 and 2 park and leave.)
+    if (wv != 0) {
+#pragma unroll
+        for (int i = 0; i < kLimbs; ++i) park[wv - 1][i][lane] = d.l[i];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    Fe b, c;
+#pragma unroll
+    for (int i = 0; i < kLimbs; ++i) { b.l[i] = park[0][i][lane]; c.l[i] = park[1][i][lane]; }
+    const u32 row = gload(S.perm + slice * kSlice + lane);
+    residual_epilogue<F>(d, b, c, row, row != kNoRow, S.out);
 }
 
 // CSR path for the listed rows only (rows too long for the SELL layout: the 2^j row of a Split gate has 257 entries,
