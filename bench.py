@@ -497,7 +497,7 @@ def main():
                        "field": a.field + "_fr", "parallelism": f"{world} rank(s) x {a.copies} independent systems (weak scaling), 1 verdict all-reduce per {ring} steps" if use_dist else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "acx::k_r1cs_sell", "kernel_us": kernel_us,
+                         "kernel": "acx::k_r1cs_sell_split", "kernel_us": kernel_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         out.update(dist_extra)
