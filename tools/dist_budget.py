@@ -5,7 +5,8 @@ four-step transform take (world, rank) as plain arguments, the rank's block-cycl
 row source, and the all-to-all moves a known number of bytes.  Prints microseconds per local step (HIP events on
 libacx's stream) and the exchange volume, from which the 8-GPU time of one distributed h(x) follows:
 
-    t = residual_dots + 3 * (inv0 + inv1) + 3 * (fwd0c + fwd1) + pointwise + (inv0 + inv1c) + 7 * exchange + all-reduce
+    t = residual_dots + 3 * (inv0 + inv1) + 2 * (fwd0c + fwd1) + pointwise + (inv0 + inv1c) + sub_o + 6 * exchange + all-reduce
+(six transforms: O(x) stays in coefficient form)
 
 python tools/dist_budget.py [--world 8] [--logn 24]   (run under rocprofv3 --kernel-trace for the kernel view)"""
 import argparse
@@ -69,17 +70,18 @@ def main():
     t["residual_dots"] = timed(stream, lambda: r.verify_dev(dw.data_ptr(), res.data_ptr(), d_dots=dots.data_ptr()))
     t["residual_only"] = timed(stream, lambda: r.verify_dev(dw.data_ptr(), res.data_ptr()))
     assert int(res[0]) == 0
-    t["pointwise"] = timed(stream, lambda: ctx.qap_pointwise_dev(dots.data_ptr(), dots[L:].data_ptr(), dots[2 * L:].data_ptr(), y.data_ptr(), L, ln, g))
+    t["pointwise"] = timed(stream, lambda: ctx.qap_pointwise_dev(dots.data_ptr(), dots[L:].data_ptr(), None, y.data_ptr(), L, ln, g))
+    t["sub_o"] = timed(stream, lambda: ctx.qap_sub_o_dev(y.data_ptr(), dots[2 * L:].data_ptr(), L, ln, g))
     xbytes = L * 32 * (W - 1) // W
-    local = t["residual_dots"] + 3 * (t["inv0"] + t["inv1"]) + 3 * (t["fwd0c"] + t["fwd1"]) + t["pointwise"] + t["inv0"] + t["inv1c"]
+    local = t["residual_dots"] + 3 * (t["inv0"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["pointwise"] + t["inv0"] + t["inv1c"] + t["sub_o"]
     print(f"rank-local budget of a {W}-rank job, N = 2^{ln} = 2^{lr} x 2^{ln - lr}, {a.field} Fr, {L} elements per rank (us):")
     for k, v in t.items():
         print(f"  {k:14s} {v:10.1f}")
-    print(f"  all-to-all: {xbytes / 2**20:.1f} MiB out per rank per transform ({xbytes // (W - 1) / 2**20:.2f} MiB per peer); 7 per h(x)")
+    print(f"  all-to-all: {xbytes / 2**20:.1f} MiB out per rank per transform ({xbytes // (W - 1) / 2**20:.2f} MiB per peer); 6 per h(x)")
     for bw in (50e9, 100e9, 153e9):
         ex = xbytes / (7 * bw) * 1e6 if W > 1 else 0.0
-        print(f"  h(x) per rank: local {local:9.1f} us + 7 exchanges at {bw / 1e9:.0f} GB/s/link x 7 links {7 * ex:8.1f} us = {local + 7 * ex:9.1f} us"
-              f" -> {(1 << ln) / (local + 7 * ex) * 1e6:.3e} constraints/s over {W} GPUs")
+        print(f"  h(x) per rank: local {local:9.1f} us + 6 exchanges at {bw / 1e9:.0f} GB/s/link x 7 links {6 * ex:8.1f} us = {local + 6 * ex:9.1f} us"
+              f" -> {(1 << ln) / (local + 6 * ex) * 1e6:.3e} constraints/s over {W} GPUs")
     dnt = t["fwd0"] + t["fwd1"]
     print(f"  one forward transform per rank: {dnt:.1f} us local (+ exchange)")
 
