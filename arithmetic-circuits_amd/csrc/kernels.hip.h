@@ -175,6 +175,9 @@ __device__ __forceinline__ uint2 gload(const uint2* p) {
     return make_uint2(r.x, r.y);
 }
 __device__ __forceinline__ u32 gload(const u32* p) { return *(g_u32*)p; }
+// a wave-uniform word through the scalar cache (constant address space: s_load_dword)
+typedef __attribute__((address_space(4))) const u32 c_u32;
+__device__ __forceinline__ u32 sload(const u32* p) { return *(c_u32*)(unsigned long long)p; }
 // The constraint stream is read exactly once per verification: non-temporal loads keep it from
 // evicting the witness window (re-read by every row) out of the XCD's L2.
 __device__ __forceinline__ uint4 nt_load(const uint4* p) {
@@ -193,7 +196,7 @@ __device__ __forceinline__ Fe fe_gload(const uint4* p) {
 
 template <class F, bool UNIT>
 __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane) {
-    const u32 q0 = gload(M.slice_ofs + slice), q1 = gload(M.slice_ofs + slice + 1);   // wave-uniform
+    const u32 q0 = sload(M.slice_ofs + slice), q1 = sload(M.slice_ofs + slice + 1);   // wave-uniform: scalar loads
     Fe acc = fe_zero();
     if (UNIT) {
         for (u32 q = q0; q < q1; ++q) {
@@ -242,7 +245,7 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
 // slot q is accumulated.
 template <class F>
 __device__ __forceinline__ Fe sell_dot_small(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane) {
-    const u32 q0 = gload(M.slice_ofs + slice), q1 = gload(M.slice_ofs + slice + 1);   // wave-uniform
+    const u32 q0 = sload(M.slice_ofs + slice), q1 = sload(M.slice_ofs + slice + 1);   // wave-uniform: scalar loads
     static_assert(kSellMaxLen <= kWideTerms, "column bound of small_reduce");
     if (q0 == q1) return fe_zero();
     i64 acc[kLimbs];
@@ -395,6 +398,8 @@ __global__ __launch_bounds__(3 * kSlice) void k_r1cs_sell_split(const SellSystem
     constexpr bool kMixed = SPEC == 2;
     __shared__ u32 park[2][kLimbs][kSlice];
     Fe d;
+    u32 row = kNoRow;
+    if (wv == 0) row = gload(S.perm + slice * kSlice + lane);              // needed last: issued first, off the wave's critical path
     if (wv == 0) d = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
     else if (wv == 1) d = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
     else d = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
@@ -410,7 +415,6 @@ __global__ __launch_bounds__(3 * kSlice) void k_r1cs_sell_split(const SellSystem
     Fe b, c;
 #pragma unroll
     for (int i = 0; i < kLimbs; ++i) { b.l[i] = park[0][i][lane]; c.l[i] = park[1][i][lane]; }
-    const u32 row = gload(S.perm + slice * kSlice + lane);
     residual_epilogue<F>(d, b, c, row, row != kNoRow, S.out);
 }
 

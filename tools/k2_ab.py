@@ -10,6 +10,8 @@ for rnd in range(3):
         env = dict(os.environ)
         if v == "old":
             env["ACX_SELL_SPLIT"] = "0"
+        elif v.endswith(".so"):
+            env["ACX_LIB"] = os.path.abspath(v)         # another build of the library (A/B of two source states on one box)
         else:
             env["ACX_K2_VARIANT"] = v
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-ntt", "--sustain", "0.3"], env=env, capture_output=True, text=True)
