@@ -13,7 +13,7 @@ for rnd in range(3):
         elif v.endswith(".so"):
             env["ACX_LIB"] = os.path.abspath(v)         # another build of the library (A/B of two source states on one box)
         else:
-            env["ACX_K2_VARIANT"] = v
+            env["ACX_K2_MULTI"] = v
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-ntt", "--sustain", "0.3"], env=env, capture_output=True, text=True)
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         res[v].append((d["roofline"]["kernel_us"], d["sustained"]["us_per_step_median"], d["config"]["single_system_launch_us"]))
