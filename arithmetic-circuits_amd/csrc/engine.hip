@@ -819,7 +819,7 @@ inline int sell_spec(const acx_r1cs* r) {
 }
 inline int sell_spec_join(int a, int b) { return a == b ? a : 2; }
 
-// grid.x is sized by sell_grid_x for the launch's largest system.  Default: the wave-specialised kernel (three waves per
+// grid.x is sized by sell_grid_x for the launch's largest system.  Default: the wave-specialised kernel (two waves per
 // slice); ACX_SELL_SPLIT=0 selects the one-wave-per-slice kernel (kept for A/B measurements, tools/split_sweep.py).
 inline bool sell_split() {
     static const bool on = [] { const char* e = getenv("ACX_SELL_SPLIT"); return !e || atoi(e) != 0; }();
@@ -828,9 +828,9 @@ inline bool sell_split() {
 inline void launch_sell(acx_ctx* c, int spec, dim3 grid, const SellSystem* systems, const SellSystem& one) {
     if (sell_split()) {
         DISPATCH_FIELD(c, {
-            if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell_split<F, 0>), grid, dim3(3 * kSlice), 0, cur_stream(c), systems, one);
-            else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell_split<F, 1>), grid, dim3(3 * kSlice), 0, cur_stream(c), systems, one);
-            else hipLaunchKernelGGL((k_r1cs_sell_split<F, 2>), grid, dim3(3 * kSlice), 0, cur_stream(c), systems, one);
+            if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell_split<F, 0>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
+            else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell_split<F, 1>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
+            else hipLaunchKernelGGL((k_r1cs_sell_split<F, 2>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
         });
         return;
     }

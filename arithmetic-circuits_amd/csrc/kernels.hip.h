@@ -378,18 +378,18 @@ __global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restri
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
 }
 
-// K2, wave-specialised form: a slice takes THREE waves, one per matrix -- wave 0 forms <A,w>, wave 1 <B,w>, wave 2 <C,w>
-// (for the unit C of every gate the reference emits that is gathers and additions only); waves 1 and 2 park their dot
-// products in LDS and leave, wave 0 does the closing a*b - c test.  Against one wave walking A, B, C in turn: a slice's three
-// streams are in flight together, multiplier-bound waves (A, B) and a memory-bound one (C) share every SIMD, nothing waits
-// in LDS while another dot product is formed (75 VGPRs = 6 waves per SIMD instead of 90 = 5), and a launch too small to
-// fill the chip (configs[1] taken literally: 2^16 rows = 1024 slices) costs one dot product's latency, not three.
-// Measured (tools/split_sweep.py, one system; both kernels with the descriptor in scalar registers): 2^16 rows 6.9 -> 5.8 us,
-// 2^21 119.4 -> 116.3 us; the bench's 32 x 2^16 rows 120.4 -> 116.8 us.  Forcing 7 waves per SIMD (72 VGPRs, 24 bytes of
-// scratch) costs 25 % (145.9 us).
+// K2, wave-specialised form: a slice takes TWO waves.  Wave 0 forms <A,w>, parks it in LDS and leaves; wave 1 forms <B,w>
+// (which waits in LDS meanwhile: 77 VGPRs = 6 waves per SIMD), then <C,w> -- for the unit C of every gate the reference
+// emits that is gathers and additions only -- and does the closing a*b - c test.  Against one wave walking A, B, C in turn
+// (k_r1cs_sell): a slice's streams are in flight together, waves of different instruction mix share every SIMD, and a
+// launch too small to fill the chip (configs[1] taken literally: 2^16 rows = 1024 slices) costs less than the sum of three
+// dot products' latencies.  The closer is the wave with the LONGER job, so it never sits in the barrier holding a wave slot
+// (the first form of this kernel, three waves with the closing test on the wave that finishes first, lost 15 % to that).
+// Same box, alternating processes (tools/k2_ab.py, bench workload, us per launch): one wave per slice 120.3, three waves
+// (A + closing | B | C) 118.1, two waves (A + closing | B, C) 115.2, this form 114.7.
 // blockIdx.y selects the system of a batched launch; XCD-contiguous slice order as in k_r1cs_sell.  SPEC as there.
 template <class F, int SPEC = 0>
-__global__ __launch_bounds__(3 * kSlice) void k_r1cs_sell_split(const SellSystem* __restrict__ systems, SellSystem one) {
+__global__ __launch_bounds__(2 * kSlice) void k_r1cs_sell_split(const SellSystem* __restrict__ systems, SellSystem one) {
     const SellSystem S = sell_system_of_launch(systems, one);               // batched : single
     const u32 per_xcd = (S.n_slices + 7) / 8;
     const u32 slice = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -397,25 +397,26 @@ __global__ __launch_bounds__(3 * kSlice) void k_r1cs_sell_split(const SellSystem
     const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kSlice), lane = threadIdx.x % kSlice;
     constexpr bool kMixed = SPEC == 2;
     __shared__ u32 park[2][kLimbs][kSlice];
-    Fe d;
+    Fe b = fe_zero(), c = b;
     u32 row = kNoRow;
-    if (wv == 0) row = gload(S.perm + slice * kSlice + lane);              // needed last: issued first, off the wave's critical path
-    if (wv == 0) d = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
-    else if (wv == 1) d = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
-    else d = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
-             : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
-    // Wave 0 closes.  (Closing on the C wave, which is done first, is SLOWER -- 133 against 117 us on 2^21 rows: it would sit
-    // in the barrier holding its wave slot until the two multiplier waves arrive, whereas here waves 1 and 2 park and leave.)
-    if (wv != 0) {
+    if (wv == 0) {
+        const Fe a = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
 #pragma unroll
-        for (int i = 0; i < kLimbs; ++i) park[wv - 1][i][lane] = d.l[i];
+        for (int i = 0; i < kLimbs; ++i) park[0][i][lane] = a.l[i];
+    } else {
+        row = gload(S.perm + slice * kSlice + lane);                        // needed last: issued first
+        b = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
+#pragma unroll
+        for (int i = 0; i < kLimbs; ++i) park[1][i][lane] = b.l[i];         // own wave's LDS traffic is ordered: no barrier
+        c = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
+            : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
     }
     __syncthreads();
-    if (wv != 0) return;
-    Fe b, c;
+    if (wv == 0) return;
+    Fe a;
 #pragma unroll
-    for (int i = 0; i < kLimbs; ++i) { b.l[i] = park[0][i][lane]; c.l[i] = park[1][i][lane]; }
-    residual_epilogue<F>(d, b, c, row, row != kNoRow, S.out);
+    for (int i = 0; i < kLimbs; ++i) { a.l[i] = park[0][i][lane]; b.l[i] = park[1][i][lane]; }
+    residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
 }
 
 // CSR path for the listed rows only (rows too long for the SELL layout: the 2^j row of a Split gate has 257 entries,
