@@ -1854,9 +1854,10 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
     // drops one of the seven transforms.  Without the zero-knowledge terms nobody needs the plain coefficients of L0 and
     // R0, so their factor g^i rides on the inverse transform's closing multiplication.
     uint4* O0 = d + 4 * N;
-    int fused = zk ? ACX_ERR_UNSUPPORTED : ntt_dev_locked(c, d, r->log_n, 2, 1, nullptr, &g);
+    // fused: all three inverse transforms in one batched launch with g^i riding; O then holds o_i g^i and the closing
+    // subtraction multiplies by g^-i from the two-level table (k_axpy_geo)
+    int fused = zk ? ACX_ERR_UNSUPPORTED : ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr, &g);
     if (fused == ACX_OK) {
-        ACX_TRY(ntt_dev_locked(c, O0, r->log_n, 1, 1, nullptr));
         ACX_TRY(ntt_dev_locked(c, d, r->log_n, 2, 0, nullptr));
     } else {
         ACX_TRY(ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr));
@@ -1878,6 +1879,11 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
                                dev_arg(hf, dl[0]), dev_arg(hf, dl[1]), dev_arg(hf, mzinv));
             hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, cur_stream(c), d_h, N, dev_arg(hf, hf.add(d12, dl[2])), dev_arg(hf, d12));
         });
+    } else if (fused == ACX_OK) {
+        uint4 *glo = nullptr, *ghi = nullptr;
+        ACX_TRY(get_coset_tables(c, hf.inv(g), r->log_n, 0, &glo, &ghi, 0));
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy_geo<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, (const uint4*)O0, N,
+                                             (const uint4*)glo, (const uint4*)ghi, dev_arg(hf, mzinv)));
     } else {
         DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, (const uint4*)nullptr,
                                              (const uint4*)nullptr, (const uint4*)O0, N, dev_arg(hf, mzinv), dev_arg(hf, mzinv), dev_arg(hf, mzinv)));

@@ -699,6 +699,20 @@ __global__ __launch_bounds__(kBlock) void k_axpy3(uint4* __restrict__ h, const u
     }
 }
 
+// h[i] += scale * base^i * x[i] with base^i from the two-level table lo[i & 1023] * hi[i >> 10] (hi == nullptr: lo[i]).
+// The h(x) pipeline's subtraction of O / z when O's coefficients still carry the coset factor g^i of the fused inverse
+// transform (base = 1/g, scale = -1/z): all three inverse transforms stay one batched launch.
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_axpy_geo(uint4* __restrict__ h, const uint4* __restrict__ x, u64 n,
+                                                    const uint4* __restrict__ lo, const uint4* __restrict__ hi, FeArg scale_arg) {
+    const Fe scale = fe_from_arg(scale_arg);
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
+        Fe f = fe_mul<F>(scale, fe_load(lo + 2 * (i & 1023u)));
+        if (hi != nullptr) f = fe_mul<F>(f, fe_load(hi + 2 * (i >> 10)));
+        fe_store(h + 2 * i, fe_add<F>(fe_load(h + 2 * i), fe_mul<F>(f, fe_load(x + 2 * i))));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Naive-roots path: `createPolynomials` (src/QAP.hs:486-508) = Lagrange interpolation on ARBITRARY
 // distinct roots with target T(x) = prod (x - r_i).  The reference calls its own version "terrible
