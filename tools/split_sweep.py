@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""verify_dev latency of ONE device-resident system at n = 2^10 ... 2^19, for the three-waves-per-slice kernel
-(k_r1cs_sell_split) against the throughput kernel: run twice, ACX_SELL_SPLIT_MAX=0 and =1000000.  python tools/split_sweep.py"""
+"""verify_dev latency of ONE device-resident system at n = 2^10 ... 2^19, for the wave-specialised kernel
+(k_r1cs_sell_split, two waves per slice) against the one-wave-per-slice kernel: run twice, ACX_SELL_SPLIT=1 and =0;
+LNS=10,16,21 selects the sizes.  python tools/split_sweep.py"""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,4 +23,4 @@ for ln in [int(x) for x in os.environ.get("LNS", "10,11,12,13,14,15,16,17,18,19"
     us = kbench.time_stream(stream, lambda: r.verify_dev(dw.data_ptr(), res.data_ptr()), 300)
     assert int(res[0]) == 0
     out.append(f"2^{ln}: {us:6.1f}")
-print("ACX_SELL_SPLIT_MAX=%s  verify_dev us:  " % os.environ.get("ACX_SELL_SPLIT_MAX", "default") + "  ".join(out))
+print("ACX_SELL_SPLIT=%s  verify_dev us:  " % os.environ.get("ACX_SELL_SPLIT", "1") + "  ".join(out))
