@@ -1224,6 +1224,29 @@ def test_small_coefficient_mulgraph_h_and_columns(request, acx, field):
 
 
 # ------------------------------------------------------------------ build once, verify many (host buffers)
+def test_verify_many_alternating_systems_reuse_descriptor_memory(request, acx):
+    """The batched residual kernel reads its per-witness system descriptors through the scalar cache (constant address
+    space).  acx_r1cs_verify_many writes them to the SAME device address on every call of a thread, so two different systems
+    verified alternately -- different matrices, sizes and witness counts, one of them with corrupted witnesses -- must each
+    see their own descriptors (a stale scalar-cache line would verify the wrong system)."""
+    ctx, orc = _ctx(request, "bn254"), _orc(request, "bn254")
+    synth = __import__("importlib").import_module("arithmetic-circuits_amd.synth")
+    sa = synth.mulgraph(1 << 10, n_in=16, window=64, seed=501)
+    sb = synth.mulgraph(3000, n_in=40, window=200, seed=502)
+    ra, rb = sa.circuit.to_r1cs(ctx), sb.circuit.to_r1cs(ctx)
+    wa, wb = sa.witness(), sb.witness()
+    Wa = np.stack([wa] * 5)
+    Wb = np.stack([wb] * 3)
+    Wb[1, 77, 0] ^= np.uint64(1)
+    _, nb, fb = orc.r1cs_residuals(rb.n, rb.m, *sb.rows(), Wb[1])
+    assert nb > 0
+    for rep in range(6):
+        ok, nbad, first = ra.verify_many(Wa)
+        assert ok.all() and not nbad.any()
+        ok, nbad, first = rb.verify_many(Wb)
+        assert list(ok) == [True, False, True] and (int(nbad[1]), int(first[1])) == (nb, fb)
+
+
 @pytest.mark.parametrize("field", ["bn254", "bls12_381"])
 def test_verify_many_matches_single_calls_and_oracle(request, acx, field):
     """acx_r1cs_verify_many = `all (verifyAssignment qap . generateAssignment program) inputs`
