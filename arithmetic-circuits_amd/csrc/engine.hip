@@ -511,8 +511,12 @@ inline int r4_pick_lg(int lp, int want) {      // largest compiled LG <= want, o
 // post_mont (inverse transforms without a coset shift only): the coefficients are multiplied by post^i on the way out --
 // "interpolate, then move to the coset post*<omega>" in one closing multiplication (the h(x) pipeline).  Returns
 // ACX_ERR_UNSUPPORTED when this size has no such fused form; the caller then takes the two-step route.
+// post_batches (with post_mont): only the first post_batches vectors of the batch take the post factor, the others end as a
+// plain inverse transform; *post_limited reports whether this plan could do that (it needs 1/N folded into the twiddles, i.e.
+// two or more passes) -- if not, every vector takes the factor.
 int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inverse, const H256* shift_mont,
-                   const H256* post_mont = nullptr) {
+                   const H256* post_mont = nullptr, uint64_t post_batches = 0, bool* post_limited = nullptr) {
+    if (post_limited) *post_limited = false;
     if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
     if (batch == 0) return ACX_OK;
     const HostField& hf = c->hf;
@@ -676,6 +680,10 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
             Q.scale_mode = (inverse && shift_mont) ? 2 : 1;
             if (r4 && Q.scale_mode == 1 && (!inverse || fold_scale)) Q.scale_mode = 0;   // nothing left to multiply by
             if (direct_coset) Q.scale_mode = 3;                                           // one product from the direct table
+            if (direct_coset && post_mont && fold_scale && post_batches > 0 && post_batches < batch) {
+                Q.scale_off_end = post_batches * N;
+                if (post_limited) *post_limited = true;
+            }
         }
         Q.stride_t_in_hi = Q.stride_t_in;      // single stride in the transform direction (split = 0)
         Q.stride_t_out_hi = Q.stride_t_out;
@@ -1854,9 +1862,11 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
     // drops one of the seven transforms.  Without the zero-knowledge terms nobody needs the plain coefficients of L0 and
     // R0, so their factor g^i rides on the inverse transform's closing multiplication.
     uint4* O0 = d + 4 * N;
-    // fused: all three inverse transforms in one batched launch with g^i riding; O then holds o_i g^i and the closing
-    // subtraction multiplies by g^-i from the two-level table (k_axpy_geo)
-    int fused = zk ? ACX_ERR_UNSUPPORTED : ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr, &g);
+    // fused: all three inverse transforms in one batched launch, g^i riding on L and R.  Plans of two or more passes leave O
+    // plain (its closing step is the multiplication-free reduction); single-pass sizes put g^i on O too and the closing
+    // subtraction takes it off again from the two-level table (k_axpy_geo)
+    bool o_plain = false;           // O came out of the batched launch WITHOUT the coset factor (plans of two or more passes)
+    int fused = zk ? ACX_ERR_UNSUPPORTED : ntt_dev_locked(c, d, r->log_n, 3, 1, nullptr, &g, 2, &o_plain);
     if (fused == ACX_OK) {
         ACX_TRY(ntt_dev_locked(c, d, r->log_n, 2, 0, nullptr));
     } else {
@@ -1879,7 +1889,7 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
                                dev_arg(hf, dl[0]), dev_arg(hf, dl[1]), dev_arg(hf, mzinv));
             hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, cur_stream(c), d_h, N, dev_arg(hf, hf.add(d12, dl[2])), dev_arg(hf, d12));
         });
-    } else if (fused == ACX_OK) {
+    } else if (fused == ACX_OK && !o_plain) {
         uint4 *glo = nullptr, *ghi = nullptr;
         ACX_TRY(get_coset_tables(c, hf.inv(g), r->log_n, 0, &glo, &ghi, 0));
         DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy_geo<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, (const uint4*)O0, N,

@@ -555,6 +555,8 @@ struct NttPass {
     u32 scale_mode;        // 0 none, 1 multiply by `scale`, 2 scale * g^(element index) via sc_lo/sc_hi, 3 (k_ntt_r4) g^(index) from the direct table sc_lo
     u32 scale_on_load;     // coset pre-multiplication of a forward transform (first pass)
     u32 pad;
+    u64 scale_off_end;     // scale_mode 3 (k_ntt_r4): outputs at offsets >= this take the plain reduction (0 = no bound): the
+                           // leading vectors of a batch get the coset factor, the rest do not (h(x): L and R, not O)
     u64 tw_mask;
     u64 stride_t_in, stride_t_out;   // transform direction
     u64 stride_c_in, stride_c_out;   // column direction

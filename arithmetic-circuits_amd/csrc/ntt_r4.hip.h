@@ -274,6 +274,8 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
             const bool tw = P.tw_mode == 2;
             const u64 ex = P.e_mode ? (P.e_base + (u64)kd * P.e_t + I * P.e_c) : (off & P.idx_mask);
             f = two_level_pow<F>(tw ? P.tw_lo : P.sc_lo, tw ? P.tw_hi : P.sc_hi, tw ? ((I * K) & P.tw_mask) : ex);
+        } else if (P.scale_mode == 3 && P.scale_off_end != 0 && off >= P.scale_off_end) {
+            mul = false;                                     // a vector of the batch that does not take the coset factor
         } else if (P.scale_mode == 3) {                      // direct coset table: g^(element index), 1/N included
             const u64 I = P.i_base + I0 + (u64)col * P.c_iw;
             f = fe_load(P.sc_lo + 2 * (P.e_mode ? (P.e_base + (u64)kd * P.e_t + I * P.e_c) : (off & P.idx_mask)));
