@@ -1223,6 +1223,19 @@ def test_small_coefficient_mulgraph_h_and_columns(request, acx, field):
     ctx0.close()
 
 
+@pytest.mark.gpu
+def test_one_wave_per_slice_kernel_stays_bit_exact():
+    """k_r1cs_sell (one wave per slice) is kept beside the wave-specialised default for A/B measurements
+    (ACX_SELL_SPLIT=0): the differential fuzz against the C oracle -- random shapes, all three matrix forms, long rows,
+    both fields -- must pass on it too."""
+    _need_gpu()
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_r1cs.py"), "25"], cwd=root,
+                         env=dict(os.environ, ACX_SELL_SPLIT="0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
 # ------------------------------------------------------------------ build once, verify many (host buffers)
 def test_verify_many_alternating_systems_reuse_descriptor_memory(request, acx):
     """The batched residual kernel reads its per-witness system descriptors through the scalar cache (constant address
