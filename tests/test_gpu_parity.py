@@ -1040,6 +1040,26 @@ def test_cpp_host_distributed_ntt_with_rccl_world1(request, tmp_path):
         assert out.returncode == 0 and "round trip exact" in out.stdout, (out.stdout, out.stderr[-2000:])
 
 
+def test_cpp_host_distributed_qap_h_with_rccl_world1(request, tmp_path):
+    """examples/dist_qap_h_rccl.cpp: verificationWitness over ranks from a C++ host with RCCL and no Python -- rank-local
+    block-cyclic rows, residual dots in ROWS layout, 3 inverse + 2 coset + 1 inverse-coset distributed transforms,
+    pointwise, O / z in coefficient form, one verdict all-reduce -- here with a one-rank communicator: the block of h(x)
+    equals the single-GPU acx_qap_h coefficient by coefficient for a satisfying and for a corrupted witness (2^12: odd
+    digit split 6 + 6; 2^17: 8 + 9)."""
+    import os, subprocess
+    _ctx(request, "bn254")
+    root = os.path.join(os.path.dirname(__file__), "..")
+    libdir = os.path.abspath(os.path.join(root, "arithmetic-circuits_amd"))
+    exe = str(tmp_path / "dist_qap_h_rccl")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "dist_qap_h_rccl.cpp"),
+                    "-L", libdir, "-lacx", "-lrccl", f"-Wl,-rpath,{libdir}", "-o", exe], check=True, capture_output=True, text=True)
+    for log_n in ("12", "17"):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", ACX_LOG_N=log_n))
+        assert out.returncode == 0 and "every block exact" in out.stdout, (out.stdout, out.stderr[-2000:])
+        assert "pass 0: satisfying witness, 0 violated rows" in out.stdout and "pass 1: corrupted witness, 1 violated rows" in out.stdout
+
+
 def test_qap_columns_device_variant_and_batches(request, acx):
     """acx_qap_columns_dev (coefficients and stripped lengths stay on the device; column view built on the device)
     == the host variant == the C oracle, for all three matrices, a wire range that starts mid-way, columns that are
