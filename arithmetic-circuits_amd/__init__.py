@@ -4,7 +4,7 @@ import it with importlib (`importlib.import_module("arithmetic-circuits_amd")`) 
 `acx` alias that tests/conftest.py, bench.py and __graft_entry__.py register."""
 from . import _lib
 from ._lib import AcxError
-from .engine import Batch, Circuit, Context, Naive, R1CS, fr_to_ints, ints_to_fr
+from .engine import Batch, Circuit, Context, MgR1CS, MultiGpu, Naive, R1CS, fr_to_ints, ints_to_fr
 from .circuit import (Add, ArithCircuit, ConstGate, Equal, InputWire, IntermediateWire, Mul, OutputWire,
                       ScalarMul, Split, Var, Wire, freshRoots, generateRoots, unsplit)
 from .qap import (GenQAP, NaiveQAP, QAP, QapSet, arithCircuitToGenQAP, arithCircuitToQAP, arithCircuitToQAPFFT,

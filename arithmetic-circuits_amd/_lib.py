@@ -95,6 +95,24 @@ SYMBOLS = {
     "acx_batch_create": (_I, [_P, _U64, _P, _P, _P, _U64, C.POINTER(_P)]),
     "acx_batch_verify_dev": (_I, [_P]),
     "acx_batch_destroy": (None, [_P]),
+    "acx_mgpu_create": (_I, [_I, C.POINTER(_I), _U32, C.POINTER(_P)]),
+    "acx_mgpu_destroy": (None, [_P]),
+    "acx_mgpu_info": (_I, [_P, C.POINTER(_U32), C.POINTER(_I), C.POINTER(_U32)]),
+    "acx_mgpu_ctx": (_P, [_P, _U32]),
+    "acx_mgpu_set_shard_threshold": (_I, [_P, _U32]),
+    "acx_mgpu_set_root": (_I, [_P, _U32, _P]),
+    "acx_mgpu_sync": (_I, [_P]),
+    "acx_mgpu_r1cs_load": (_I, [_P, _U64, _U64, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), C.POINTER(_P)]),
+    "acx_mgpu_circuit_to_r1cs": (_I, [_P, _P, _P, _U64, C.POINTER(_P)]),
+    "acx_mgpu_r1cs_destroy": (None, [_P]),
+    "acx_mgpu_r1cs_dims": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U32), C.POINTER(_U32)]),
+    "acx_mgpu_r1cs_verify": (_I, [_P, _P, C.POINTER(_I), C.POINTER(_U64), C.POINTER(_U64)]),
+    "acx_mgpu_qap_h": (_I, [_P, _P, _P, _P, C.POINTER(_U64), C.POINTER(_I)]),
+    "acx_mgpu_ntt": (_I, [_P, _U32, _I, _P, _P, _P]),
+    "acx_mgpu_witness_upload": (_I, [_P, _P]),
+    "acx_mgpu_r1cs_verify_resident": (_I, [_P, C.POINTER(_I), C.POINTER(_U64), C.POINTER(_U64)]),
+    "acx_mgpu_qap_h_resident": (_I, [_P, _P, C.POINTER(_I)]),
+    "acx_mgpu_qap_h_fetch": (_I, [_P, _P, C.POINTER(_U64)]),
 }
 
 _lib = None

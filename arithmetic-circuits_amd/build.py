@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libacx.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["fr.hip.h", "kernels.hip.h", "ntt_r4.hip.h", "field_consts.h", "host_field.h", "circuit_host.h",
+HEADERS = ["fr.hip.h", "kernels.hip.h", "ntt_r4.hip.h", "field_consts.h", "host_field.h", "circuit_host.h", "mgpu.inc.h",
            os.path.join("..", "..", "include", "acx.h")]
 
 
@@ -25,7 +25,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", "-pthread"] + os.environ.get("ACX_EXTRA_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+           "-Wno-unused-function", "-pthread", "-ldl"] + os.environ.get("ACX_EXTRA_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

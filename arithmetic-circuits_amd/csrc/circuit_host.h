@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <exception>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <map>
@@ -32,19 +34,37 @@ struct SparseRow {
 // arithCircuitToGenQAP, src/QAP.hs:530-539).  ACX_HOST_THREADS overrides the count.
 inline unsigned host_threads(uint64_t items, uint64_t grain) {
     unsigned t = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 64u, (unsigned)(items / grain + 1)});
-    if (const char* e = std::getenv("ACX_HOST_THREADS")) t = (unsigned)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("ACX_HOST_THREADS")) t = (unsigned)std::min(256, std::max(1, std::atoi(e)));
     return t;
 }
-// body(t, begin, end) over a partition of [0, n) into T contiguous ranges; std::bad_alloc is carried to the caller
+// body(t, begin, end) over a partition of [0, n) into T contiguous ranges.  Nothing may escape a worker thread or leave a
+// joinable std::thread behind (either is std::terminate, which would cross the C ABI): a worker's exception is carried to
+// the caller and rethrown after the join, and ranges whose thread could not be created (std::system_error at the thread
+// limit) run on the calling thread.
 template <class Body>
 inline void parallel_ranges(uint64_t n, unsigned T, Body&& body) {
     if (T <= 1) { body(0u, (uint64_t)0, n); return; }
-    std::atomic<bool> oom{false};
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto run = [&](unsigned t) {
+        try {
+            body(t, n * t / T, n * (t + 1) / T);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (!err) err = std::current_exception();
+        }
+    };
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; ++t)
-        th.emplace_back([&, t] { try { body(t, n * t / T, n * (t + 1) / T); } catch (const std::bad_alloc&) { oom = true; } });
+    unsigned started = 0;
+    try {
+        th.reserve(T);
+        for (; started < T; ++started) th.emplace_back(run, started);
+    } catch (...) {
+        // fall through: the ranges [started, T) run inline below
+    }
+    for (unsigned t = started; t < T; ++t) run(t);
     for (auto& x : th) x.join();
-    if (oom) throw std::bad_alloc();
+    if (err) std::rethrow_exception(err);
 }
 
 struct HostCsr {

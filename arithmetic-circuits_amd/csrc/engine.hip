@@ -1,12 +1,15 @@
 // engine.hip -- libacx.so: contexts, device-resident constraint systems, kernel orchestration
-// and the C ABI of include/acx.h.  One context = one GPU (one process per GPU in multi-GPU
-// jobs; the collectives live in the host layer above this library, over RCCL).
+// and the C ABI of include/acx.h.  One acx_ctx = one GPU.  Several GPUs: either one process per GPU with the
+// collectives in the host layer (acx_ntt_dist_step_dev + RCCL: parallel.py, examples/), or ONE process and
+// an acx_mgpu handle that shards the rows, issues the RCCL collectives itself and keeps the reference's
+// one-call shape (mgpu.inc.h, included at the end of this file).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <atomic>
+#include <list>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -52,6 +55,8 @@ static int guarded(Fn&& fn) {
         return fail(ACX_ERR_OOM, "host allocation failed");
     } catch (const std::exception& e) {
         return fail(ACX_ERR_INVALID_ARG, std::string("unexpected exception: ") + e.what());
+    } catch (...) {
+        return fail(ACX_ERR_INVALID_ARG, "unexpected exception");
     }
 }
 
@@ -72,7 +77,6 @@ static int guarded(Fn&& fn) {
 // ------------------------------------------------------------------------------------ handles
 struct NttCfg {
     int impl = 1;            // 0 tile, 1 r4
-    int xchg = 0;            // 0 LDS, 1 DPP / permlane
     uint32_t tile_log = 12;
     uint32_t direct_tw = 20;
     int n_digits = 0;
@@ -99,6 +103,7 @@ struct acx_ctx {
         size_t ntt_scratch_bytes = 0;
         hipStream_t copy_stream = nullptr;     // device-to-host copies that overlap the next batch's kernels
         hipEvent_t ev[2] = {nullptr, nullptr};
+        std::vector<void*> pins;               // coset-table entries this lane's current call holds (acx_ctx::CosetTables*)
     };
     static constexpr int kLanes = 4;
     Lane lanes[kLanes];
@@ -118,8 +123,14 @@ struct acx_ctx {
         int scaled = 0;
         int direct = 0;                                    // lo = the full table g^j, j < 2^log_n (hi unused)
         uint64_t stamp = 0;
+        int pins = 0;                                      // lanes that hold the pointers (released after their stream drained)
     };
-    CosetTables cosets[8];
+    // A small LRU.  Entries handed to a lane are PINNED until that lane's call has drained its stream (LaneGuard): a lane
+    // launches after get_coset_tables has returned and released ctx->mu, so an unpinned entry could be evicted and freed by
+    // another lane in between.  Only unpinned entries are evicted; when every entry is pinned the list grows past kCosetCap
+    // and shrinks again on later misses.  (The device-pointer path launches under ctx->mu and needs no pin.)
+    static constexpr size_t kCosetCap = 8;
+    std::list<CosetTables> cosets;
     uint64_t coset_clock = 0;
     unsigned long long* d_result = nullptr;                // {n_bad, first_bad}
     uint32_t* d_err = nullptr;
@@ -136,7 +147,8 @@ static inline uint32_t* cur_err(const acx_ctx* c) { return t_lane ? t_lane->d_er
 
 struct LaneGuard {
     acx_ctx::Lane* lane = nullptr;
-    explicit LaneGuard(acx_ctx* c) {
+    acx_ctx* ctx = nullptr;
+    explicit LaneGuard(acx_ctx* c) : ctx(c) {
         for (int i = 0; i < acx_ctx::kLanes && !lane; ++i)
             if (c->lanes[i].mu.try_lock()) lane = &c->lanes[i];
         if (!lane) {
@@ -145,7 +157,17 @@ struct LaneGuard {
         }
         t_lane = lane;
     }
-    ~LaneGuard() { t_lane = nullptr; lane->mu.unlock(); }
+    ~LaneGuard() {
+        if (!lane->pins.empty()) {
+            // every successful call has synchronised its stream already; a failed one may still have kernels in flight
+            (void)hipStreamSynchronize(lane->stream);
+            CtxLock lock(ctx->mu);
+            for (void* p : lane->pins) --static_cast<acx_ctx::CosetTables*>(p)->pins;
+            lane->pins.clear();
+        }
+        t_lane = nullptr;
+        lane->mu.unlock();
+    }
     LaneGuard(const LaneGuard&) = delete;
     LaneGuard& operator=(const LaneGuard&) = delete;
 };
@@ -190,7 +212,8 @@ struct acx_r1cs {
     uint4* ev_mul = nullptr;             // per plan item: the Mul gate's record (k_eval_level)
     u32* ev_cols = nullptr;              // per plan item: kEvalLanes columns (k_eval_level_lanes)
     bool has_csc = false;
-    uint4* d_w = nullptr;  // witness staging, m elements
+    uint4* d_w = nullptr;  // the witness acx_r1cs_eval leaves resident (m elements); acx_naive_h uses it as scratch
+    bool resident_valid = false;                     // d_w holds a witness produced by acx_r1cs_eval
     uint4* qh = nullptr;   // h(x) pipeline scratch, 5N elements (allocated on first use)
 };
 
@@ -422,39 +445,54 @@ int get_scaled_table(acx_ctx* c, uint32_t log_m, uint64_t count, int inverse, ui
 // direct: ONE table of all 2^log_n powers (32 bytes each): the closing multiplication then needs no second product.
 int get_coset_tables(acx_ctx* c, const H256& base_mont, uint32_t log_n, int scaled, uint4** lo, uint4** hi, int direct = 0) {
     CtxLock lock(c->mu);
+    auto hand_out = [&](acx_ctx::CosetTables& e) {
+        e.stamp = ++c->coset_clock;
+        if (t_lane) { ++e.pins; t_lane->pins.push_back(&e); }
+        *lo = e.lo; *hi = e.hi;
+        return ACX_OK;
+    };
     for (auto& e : c->cosets)
-        if (e.lo && e.base == base_mont && e.log_n == log_n && e.scaled == scaled && e.direct == direct) {
-            e.stamp = ++c->coset_clock;
-            *lo = e.lo; *hi = e.hi;
-            return ACX_OK;
-        }
-    // evict the least recently used slot
-    acx_ctx::CosetTables* slot = &c->cosets[0];
-    for (auto& e : c->cosets) if (!e.lo || e.stamp < slot->stamp) { slot = &e; if (!e.lo) break; }
-    if (slot->lo) {
-        HIP_TRY(hipDeviceSynchronize());           // previous users of the old tables (on any lane) are done
-        (void)hipFree(slot->lo);
-        if (slot->hi) (void)hipFree(slot->hi);
-        slot->lo = slot->hi = nullptr;
+        if (e.base == base_mont && e.log_n == log_n && e.scaled == scaled && e.direct == direct) return hand_out(e);
+    // make room: drop least recently used UNPINNED entries while the list is at its cap
+    while (c->cosets.size() >= acx_ctx::kCosetCap) {
+        auto victim = c->cosets.end();
+        for (auto it = c->cosets.begin(); it != c->cosets.end(); ++it)
+            if (it->pins == 0 && (victim == c->cosets.end() || it->stamp < victim->stamp)) victim = it;
+        if (victim == c->cosets.end()) break;                        // everything is in use: grow
+        HIP_TRY(hipDeviceSynchronize());           // kernels already launched with the old tables (device-pointer path, finished lanes)
+        (void)hipFree(victim->lo);
+        if (victim->hi) (void)hipFree(victim->hi);
+        c->cosets.erase(victim);
     }
+    // build the tables first; the entry (and its key) exists only once they are complete
+    acx_ctx::CosetTables fresh;
     const uint64_t hi_count = (!direct && log_n > 10) ? (1ull << (log_n - 10)) : 0;
     const uint64_t lo_count = direct ? (1ull << log_n) : 1024;
-    HIP_TRY(hipMalloc((void**)&slot->lo, lo_count * 32));
-    const H256 first = scaled ? c->hf.inv(c->hf.from_u64(1ull << log_n)) : c->hf.one();
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(grid_for(c, lo_count)), dim3(kBlock), 0, cur_stream(c), slot->lo,
-                                         lo_count, dev_arg(c->hf, base_mont), dev_arg(c->hf, first)));
-    if (hi_count) {
-        HIP_TRY(hipMalloc((void**)&slot->hi, hi_count * 32));
-        const H256 b1024 = c->hf.pow_u64(base_mont, 1024);
-        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, hi_count)), dim3(kBlock), 0, cur_stream(c),
-                                             slot->hi, hi_count, dev_arg(c->hf, b1024)));
+    auto build = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&fresh.lo, lo_count * 32));
+        const H256 first = scaled ? c->hf.inv(c->hf.from_u64(1ull << log_n)) : c->hf.one();
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_scaled<F>), dim3(grid_for(c, lo_count)), dim3(kBlock), 0, cur_stream(c), fresh.lo,
+                                             lo_count, dev_arg(c->hf, base_mont), dev_arg(c->hf, first)));
+        if (hi_count) {
+            HIP_TRY(hipMalloc((void**)&fresh.hi, hi_count * 32));
+            const H256 b1024 = c->hf.pow_u64(base_mont, 1024);
+            DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table<F>), dim3(grid_for(c, hi_count)), dim3(kBlock), 0, cur_stream(c),
+                                                 fresh.hi, hi_count, dev_arg(c->hf, b1024)));
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(cur_stream(c)));   // other lanes may use the tables from their own streams
+        return ACX_OK;
+    };
+    const int rc = build();
+    if (rc != ACX_OK) {
+        (void)hipStreamSynchronize(cur_stream(c));
+        if (fresh.lo) (void)hipFree(fresh.lo);
+        if (fresh.hi) (void)hipFree(fresh.hi);
+        return rc;
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
-    slot->base = base_mont; slot->log_n = log_n; slot->scaled = scaled; slot->direct = direct; slot->stamp = ++c->coset_clock;
-    *lo = slot->lo;
-    *hi = slot->hi;
-    return ACX_OK;
+    fresh.base = base_mont; fresh.log_n = log_n; fresh.scaled = scaled; fresh.direct = direct;
+    c->cosets.push_back(fresh);
+    return hand_out(c->cosets.back());
 }
 
 inline uint64_t pow2_floor(uint64_t x) { uint64_t p = 1; while (p * 2 <= x) p *= 2; return p; }
@@ -465,13 +503,12 @@ inline uint32_t ilog2(uint64_t x) { uint32_t k = 0; while ((1ull << (k + 1)) <= 
 // multiplies by the inter-pass twiddle.  Two kernel families: k_ntt_tile (<= 8 bits per pass, one
 // radix-2 stage per LDS round trip; every size) and k_ntt_r4 (<= 12 bits per pass, four elements
 // per lane in registers; log_n >= 10).  Tunables (development / A-B measurements), read once per
-// context: ACX_NTT_IMPL=tile|r4, ACX_NTT_XCHG=lds|dpp, ACX_NTT_TILE_LOG (max log2 elements per r4
+// context: ACX_NTT_IMPL=tile|r4, ACX_NTT_TILE_LOG (max log2 elements per r4
 // tile, default 12), ACX_NTT_DIRECT_TW (largest log2 size of a direct inter-pass twiddle table,
 // default 20), ACX_NTT_DIGITS="10,10" (forces the digit split of every transform of that size).
 NttCfg ntt_cfg_from_env() {
     NttCfg g;
     if (const char* e = std::getenv("ACX_NTT_IMPL")) g.impl = std::string(e) == "tile" ? 0 : 1;
-    if (const char* e = std::getenv("ACX_NTT_XCHG")) g.xchg = std::string(e) == "dpp" ? 1 : 0;
     if (const char* e = std::getenv("ACX_NTT_TILE_LOG")) g.tile_log = (uint32_t)std::max(6, std::min(12, std::atoi(e)));
     if (const char* e = std::getenv("ACX_NTT_DIRECT_TW")) g.direct_tw = (uint32_t)std::max(0, std::min(24, std::atoi(e)));
     if (const char* e = std::getenv("ACX_NTT_DIGITS")) {
@@ -484,11 +521,11 @@ NttCfg ntt_cfg_from_env() {
 }
 
 // (LP, LG) instances of k_ntt_r4 that are compiled
-template <class F, int XCHG>
+template <class F>
 bool launch_r4(int lp, int lg, unsigned tiles, hipStream_t st, const NttPass& Q) {
 #define ACX_R4_CASE(LP_, LG_)                                                                                    \
     if (lp == LP_ && lg == LG_) {                                                                               \
-        hipLaunchKernelGGL((k_ntt_r4<F, LP_, LG_, XCHG>), dim3(tiles), dim3(1u << (LP_ - 2 + LG_)), 0, st, Q);   \
+        hipLaunchKernelGGL((k_ntt_r4<F, LP_, LG_>), dim3(tiles), dim3(1u << (LP_ - 2 + LG_)), 0, st, Q);   \
         return true;                                                                                            \
     }
     ACX_R4_CASE(6, 0) ACX_R4_CASE(6, 2) ACX_R4_CASE(6, 4)
@@ -692,8 +729,7 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         if (r4) {
             bool ok = false;
             DISPATCH_FIELD(c, {
-                ok = cfg.xchg == 1 ? launch_r4<F, kXchgDpp>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q)
-                                   : launch_r4<F, kXchgLds>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
+                ok = launch_r4<F>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
             });
             if (!ok) return fail(ACX_ERR_UNSUPPORTED, "NTT plan: kernel instance missing");
         } else {
@@ -797,8 +833,7 @@ int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t wo
     const uint64_t tiles = cols / T;
     bool ok = false;
     DISPATCH_FIELD(c, {
-        ok = cfg.xchg == 1 ? launch_r4<F, kXchgDpp>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q)
-                           : launch_r4<F, kXchgLds>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
+        ok = launch_r4<F>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
     });
     if (!ok) return fail(ACX_ERR_UNSUPPORTED, "distributed NTT step: kernel instance missing");
     HIP_TRY(hipGetLastError());
@@ -827,33 +862,16 @@ inline int sell_spec(const acx_r1cs* r) {
 }
 inline int sell_spec_join(int a, int b) { return a == b ? a : 2; }
 
-// grid.x is sized by sell_grid_x for the launch's largest system.  Default: the wave-specialised kernel (two waves per
-// slice); ACX_SELL_SPLIT=0 selects the one-wave-per-slice kernel (kept for A/B measurements, tools/split_sweep.py).
-inline bool sell_split() {
-    static const bool on = [] { const char* e = getenv("ACX_SELL_SPLIT"); return !e || atoi(e) != 0; }();
-    return on;
-}
+// grid.x is sized by sell_grid_x for the launch's largest system: one workgroup (two waves) per slice.
 inline void launch_sell(acx_ctx* c, int spec, dim3 grid, const SellSystem* systems, const SellSystem& one) {
-    if (sell_split()) {
-        DISPATCH_FIELD(c, {
-            if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell_split<F, 0>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
-            else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell_split<F, 1>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
-            else hipLaunchKernelGGL((k_r1cs_sell_split<F, 2>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
-        });
-        return;
-    }
     DISPATCH_FIELD(c, {
-        if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell<F, 0>), grid, dim3(kBlock), 0, cur_stream(c), systems, one);
-        else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell<F, 1>), grid, dim3(kBlock), 0, cur_stream(c), systems, one);
-        else hipLaunchKernelGGL((k_r1cs_sell<F, 2>), grid, dim3(kBlock), 0, cur_stream(c), systems, one);
+        if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell_split<F, 0>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
+        else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell_split<F, 1>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
+        else hipLaunchKernelGGL((k_r1cs_sell_split<F, 2>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
     });
 }
 
-inline unsigned sell_grid_x(uint32_t n_slices) {
-    if (sell_split()) return ((n_slices + 7) / 8) * 8;      // one workgroup per slice
-    const uint32_t tiles = (n_slices + 3) / 4;
-    return ((tiles + 7) / 8) * 8;   // multiple of 8: the XCD remap is a bijection
-}
+inline unsigned sell_grid_x(uint32_t n_slices) { return ((n_slices + 7) / 8) * 8; }   // multiple of 8: the XCD remap is a bijection
 
 // rows too long for SELL go through the CSR kernel
 int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out, const SellSystem* d_many = nullptr, uint32_t n_many = 1) {
@@ -883,10 +901,10 @@ int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out, cons
 }
 
 int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned long long* d_result,
-                    uint4* d_res, uint4* d_dots, uint64_t dots_stride) {
+                    uint4* d_res, uint4* d_dots, uint64_t dots_stride, uint32_t map_log_c = 0, uint32_t map_log_r = 0) {
     acx_ctx* c = r->ctx;
     if (r->n == 0) return ACX_OK;
-    const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset};
+    const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset, map_log_c, map_log_r};
     const SellSystem S = sell_system(r, d_w, out);
     const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
     launch_sell(c, sell_spec(r), grid, nullptr, S);
@@ -1105,7 +1123,7 @@ void free_r1cs_device(acx_r1cs* r) {
     r->perm = nullptr; r->long_rows = nullptr; r->d_w = nullptr; r->qh = nullptr;
 }
 
-int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3], acx_r1cs** out) {
+int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* const mats[3], acx_r1cs** out) {
     if (!ctx || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (m == 0 || m >= 0xffffffffull || n >= 0xffffffffull) return fail(ACX_ERR_TOO_LARGE, "n or m out of range");
     const uint32_t log_n = ceil_log2(std::max<uint64_t>(n, 1));
@@ -1192,10 +1210,8 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* mats[3],
 }
 
 // Build the CSC copies on the device from the device CSR: histogram, scan, fill (kernels.hip.h K6).
-int ensure_csc(acx_r1cs* r) {
+static int build_csc(acx_r1cs* r) {
     acx_ctx* c = r->ctx;
-    CtxLock lock(c->mu);
-    if (r->has_csc) return ACX_OK;
     const hipStream_t st = cur_stream(c);
     for (int k = 0; k < 3; ++k) {
         const DevMatrix& M = r->M[k];
@@ -1217,10 +1233,27 @@ int ensure_csc(acx_r1cs* r) {
             hipLaunchKernelGGL(k_csc_fill, dim3(grid_for(c, r->n)), dim3(kBlock), 0, st, csr, r->n, (const u32*)T.ptr, cursor.as<u32>(),
                                T.idx, T.colid, T.val);
         }
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipGetLastError());                // before the host copy of colptr is consumed
         T.h_ptr.resize(r->m + 1);
-        HIP_TRY(hipMemcpyAsync(T.h_ptr.data(), T.ptr, (r->m + 1) * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));       // count / cursor go out of scope; other lanes may use the CSC from here on
+        const hipError_t e1 = hipMemcpyAsync(T.h_ptr.data(), T.ptr, (r->m + 1) * 4, hipMemcpyDeviceToHost, st);
+        const hipError_t e2 = hipStreamSynchronize(st);       // count / cursor go out of scope; other lanes may use the CSC from here on
+        HIP_TRY(e1);
+        HIP_TRY(e2);
+    }
+    return ACX_OK;
+}
+
+// Build the CSC copies on the device from the device CSR: histogram, scan, fill (kernels.hip.h K6).  All three or none: a
+// failure part-way (device OOM on the third matrix) releases what the earlier ones allocated, so a retry starts clean.
+int ensure_csc(acx_r1cs* r) {
+    acx_ctx* c = r->ctx;
+    CtxLock lock(c->mu);
+    if (r->has_csc) return ACX_OK;
+    const int rc = build_csc(r);
+    if (rc != ACX_OK) {
+        (void)hipStreamSynchronize(cur_stream(c));
+        for (int k = 0; k < 3; ++k) free_matrix(r->T[k]);
+        return rc;
     }
     r->has_csc = true;
     return ACX_OK;
@@ -1346,6 +1379,7 @@ void acx_ctx_destroy(acx_ctx* c) {
     for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
     if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
     for (auto& e : c->cosets) { if (e.lo) (void)hipFree(e.lo); if (e.hi) (void)hipFree(e.hi); }
+    c->cosets.clear();
     if (c->d_result) (void)hipFree(c->d_result);                   // d_err lives inside it
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto& ln : c->lanes) {
@@ -1781,6 +1815,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     std::memset(w0.data(), 0, w0.size() * 32);
     w0[0].b[0] = 1;
     for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) w0[1 + i] = inputs[i];
+    r->resident_valid = false;
     HIP_TRY(hipMemsetAsync(r->d_w, 0, r->m * 32, cur_stream(c)));
     ACX_TRY(upload_elements(c, w0.data(), w0.size(), r->d_w));
     const CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val};
@@ -1801,6 +1836,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
         }
     }
     HIP_TRY(hipGetLastError());
+    r->resident_valid = true;
     if (witness) {
         DevBuf tmp;
         ACX_TRY(tmp.alloc(r->m * 32));
@@ -1816,6 +1852,8 @@ int acx_r1cs_verify_resident(acx_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* fi
     if (!r || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
     CtxLock lock(c->mu);
+    if (!r->resident_valid)
+        return fail(ACX_ERR_UNSUPPORTED, "no resident witness: acx_r1cs_eval has not run on this system (or acx_naive_h has used the buffer since)");
     HIP_TRY(hipSetDevice(c->device));
     const unsigned long long init[2] = {0ull, ~0ull};
     HIP_TRY(hipMemcpyAsync(cur_result(c), init, 16, hipMemcpyHostToDevice, cur_stream(c)));
@@ -2217,6 +2255,7 @@ int acx_naive_h(acx_naive* nv, const acx_fr* witness, const acx_fr* delta, acx_f
     HIP_TRY(hipMemsetAsync(lro.p, 0, (size_t)3 * np1 * 32, cur_stream(c)));
     HIP_TRY(hipMemsetAsync(quot.p, 0, (size_t)(np1 + 1) * 32, cur_stream(c)));
     uint64_t bad = 0;
+    r->resident_valid = false;                                     // d_w doubles as this call's witness staging
     ACX_TRY(verify_common(r, witness, r->d_w, &bad, nullptr, nullptr, dots.as<uint4>(), N));
     H256 dl[3] = {hf.zero(), hf.zero(), hf.zero()};
     if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], hf, dl[k]));
@@ -2328,3 +2367,5 @@ int acx_ntt_dev(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const a
 }
 
 }  // extern "C"
+
+#include "mgpu.inc.h"

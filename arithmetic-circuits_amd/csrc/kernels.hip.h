@@ -7,6 +7,15 @@ namespace acx {
 
 constexpr int kBlock = 256;
 
+#ifdef ACX_K2_WAVES
+#define ACX_K2_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ACX_K2_WAVES, ACX_K2_WAVES)))
+#else
+#define ACX_K2_WAVES_ATTR
+#endif
+#ifndef ACX_K2_PIPE
+#define ACX_K2_PIPE 0          // development A/B switch of the residual kernel's software pipeline (profiles/r03_r1cs.txt)
+#endif
+
 // Device CSR view (values in dev format: 2 x uint4 per entry).
 struct CsrDev {
     const u32* rowptr;
@@ -217,6 +226,37 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
     static_assert(kSellMaxLen <= kWideTerms, "a SELL row is reduced once");
     if (q0 == q1) return acc;
     Wide wide;
+#if ACX_K2_PIPE == 1
+    // Gather one slot AHEAD as well: in iteration q the gather of slot q+1 (its column arrived with the tail word loaded
+    // two slots ahead), the values of slot q+1 and the tail of slot q+2 are issued before the products of slot q, whose
+    // operands were requested a whole iteration earlier.
+    uint2 t0 = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
+    uint2 t1 = t0;
+    if (q0 + 1 < q1) t1 = nt_load(&M.tail[(u64)(q0 + 1) * kSlice + lane]);
+    uint4 lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
+    uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
+    const uint4* px = w + 2 * (u64)(t0.y == kNoRow ? 0u : t0.y);
+    uint4 xlo = gload(px), xhi = gload(px + 1);
+    for (u32 q = q0; q < q1; ++q) {
+        Fe v;
+        v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
+        v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
+        v.l[8] = t0.x;
+        const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
+        if (q + 1 < q1) {
+            const uint4* pn = w + 2 * (u64)(t1.y == kNoRow ? 0u : t1.y);
+            xlo = gload(pn);
+            xhi = gload(pn + 1);
+            lo = nt_load(&M.val[(2 * (u64)(q + 1)) * kSlice + lane]);
+            hi = nt_load(&M.val[(2 * (u64)(q + 1) + 1) * kSlice + lane]);
+            t0 = t1;
+            if (q + 2 < q1) t1 = nt_load(&M.tail[(u64)(q + 2) * kSlice + lane]);
+        }
+        const Fe x = fe_unpack(xw);
+        if (q == q0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
+    }
+    return wide_reduce<F>(wide);
+#else
     uint2 t = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
     uint4 lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
     uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
@@ -237,6 +277,7 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
         if (q == q0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
     }
     return wide_reduce<F>(wide);
+#endif
 }
 
 // <M_row, w> for a small-coefficient matrix: nine signed columns, one v_mad_i64_i32 per limb and entry, one exact
@@ -279,6 +320,10 @@ struct ResidualOut {
     uint4* dots;                 // [3 * stride] or null
     u64 dots_stride;
     u64 row_offset;
+    // first_bad numbering.  map_log_r == 0: row + row_offset (a contiguous slab of a larger system).  Otherwise the rows are a
+    // block-cyclic shard in ROWS order (include/acx.h, acx_mgpu_*): local row j = [kl][k2] with 2^map_log_c values of k2 is
+    // global row (row_offset + kl) + k2 * 2^map_log_r.  Only evaluated on the (rare) violated-row path.
+    u32 map_log_c, map_log_r;
 };
 
 // per-lane epilogue shared by the SELL and the CSR-rows kernels.  Violations are the rare case: a
@@ -299,7 +344,12 @@ __device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, cons
     }
     const unsigned long long mask = __ballot(bad);
     if (mask == 0) return;                                   // wave-uniform
-    unsigned long long my_first = bad ? (u64)row + out.row_offset : ~0ull;
+    unsigned long long my_first = ~0ull;
+    if (bad) {
+        my_first = (u64)row + out.row_offset;
+        if (out.map_log_r != 0)
+            my_first = out.row_offset + (row >> out.map_log_c) + ((u64)(row & ((1u << out.map_log_c) - 1u)) << out.map_log_r);
+    }
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_down(my_first, off, 64);
         my_first = o < my_first ? o : my_first;
@@ -337,59 +387,27 @@ __device__ __forceinline__ SellSystem sell_system_of_launch(const SellSystem* sy
     return S;
 }
 
-// K2: r_i = <A_i,w> * <B_i,w> - <C_i,w> for every row (verifyAssignment, src/QAP.hs:276-327, in the
-// evaluation domain).  One wave per slice, one lane per row; blockIdx.y selects the system of a
-// batched launch.  XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order),
-// so XCD x gets the contiguous tile range [x*T/8, (x+1)*T/8): the rows in flight on an XCD, and
-// the witness window they gather from, stay inside its private 4 MiB L2.  gridDim.x = tiles
-// rounded up to a multiple of 8.
+// K2: r_i = <A_i,w> * <B_i,w> - <C_i,w> for every row (verifyAssignment, src/QAP.hs:276-327, in the evaluation domain);
+// blockIdx.y selects the system of a batched launch.  XCD-aware slice order: workgroup b runs on XCD b % 8 (observed
+// dispatch order), so XCD x gets the contiguous slice range [x*T/8, (x+1)*T/8): the rows in flight on an XCD, and the
+// witness window they gather from, stay inside its private 4 MiB L2.  gridDim.x = slices rounded up to a multiple of 8.
 // SPEC = 0: no matrix of the launch is in the small-coefficient form (the full-width path alone).
 // SPEC = 1: every system of the launch has small-coefficient A and B and a unit C (the shape of a compiled program);
 //           the instance then carries none of the deferred-reduction path's registers (58 VGPRs, 8 waves per SIMD).
 // SPEC = 2: anything else; the form of each matrix is a run-time flag of its system.
-template <class F, int SPEC = 0>
-__global__ __launch_bounds__(kBlock) void k_r1cs_sell(const SellSystem* __restrict__ systems, SellSystem one) {
-    const SellSystem S = sell_system_of_launch(systems, one);               // batched : single
-    const u32 tiles = (S.n_slices + 3) / 4;
-    const u32 per_xcd = (tiles + 7) / 8;
-    const u32 tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    // the remap is a bijection on [0, 8*per_xcd) only: a batched launch sizes gridDim.x for its
-    // largest system, so workgroups beyond this system's own range must not run
-    if (blockIdx.x >= 8 * per_xcd || tile >= tiles) return;
-    const u32 slice = tile * 4 + threadIdx.x / kSlice, lane = threadIdx.x % kSlice;
-    // <A,w> waits in LDS while <B,w> and <C,w> are formed: nine registers less, which is what takes
-    // the kernel from 4 to 5 waves per SIMD (it is bound by memory latency x concurrency)
-    __shared__ u32 park[kLimbs][kBlock];
-    Fe a = fe_zero(), b = a, c = a;
-    u32 row = kNoRow;
-    if (slice < S.n_slices) {
-        row = gload(S.perm + slice * kSlice + lane);
-        constexpr bool kMixed = SPEC == 2;            // SPEC 0 carries no small-coefficient code at all (it costs the
-                                                      // full-width path ~2 % when merely present in the kernel)
-        a = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
-#pragma unroll
-        for (int i = 0; i < kLimbs; ++i) park[i][threadIdx.x] = a.l[i];
-        b = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
-        c = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
-            : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
-#pragma unroll
-        for (int i = 0; i < kLimbs; ++i) a.l[i] = park[i][threadIdx.x];
-    }
-    residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
-}
-
+// (Rounds 1-2 also carried `k_r1cs_sell`, one wave walking A, B, C of four slices per workgroup: 120.3 us against 114.7 us
+// per bench launch, profiles/r02_r1cs_experiments.txt item 15; removed in round 3, code in git history.)
 // K2, wave-specialised form: a slice takes TWO waves.  Wave 0 forms <A,w>, parks it in LDS and leaves; wave 1 forms <B,w>
 // (which waits in LDS meanwhile: 77 VGPRs = 6 waves per SIMD), then <C,w> -- for the unit C of every gate the reference
 // emits that is gathers and additions only -- and does the closing a*b - c test.  Against one wave walking A, B, C in turn
-// (k_r1cs_sell): a slice's streams are in flight together, waves of different instruction mix share every SIMD, and a
+// (the removed k_r1cs_sell): a slice's streams are in flight together, waves of different instruction mix share every SIMD, and a
 // launch too small to fill the chip (configs[1] taken literally: 2^16 rows = 1024 slices) costs less than the sum of three
 // dot products' latencies.  The closer is the wave with the LONGER job, so it never sits in the barrier holding a wave slot
 // (the first form of this kernel, three waves with the closing test on the wave that finishes first, lost 15 % to that).
 // Same box, alternating processes (tools/k2_ab.py, bench workload, us per launch): one wave per slice 120.3, three waves
 // (A + closing | B | C) 118.1, two waves (A + closing | B, C) 115.2, this form 114.7.
-// blockIdx.y selects the system of a batched launch; XCD-contiguous slice order as in k_r1cs_sell.  SPEC as there.
 template <class F, int SPEC = 0>
-__global__ __launch_bounds__(2 * kSlice) void k_r1cs_sell_split(const SellSystem* __restrict__ systems, SellSystem one) {
+__global__ __launch_bounds__(2 * kSlice) ACX_K2_WAVES_ATTR void k_r1cs_sell_split(const SellSystem* __restrict__ systems, SellSystem one) {
     const SellSystem S = sell_system_of_launch(systems, one);               // batched : single
     const u32 per_xcd = (S.n_slices + 7) / 8;
     const u32 slice = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -677,12 +695,13 @@ __global__ __launch_bounds__(kBlock) void k_pointwise_h(const uint4* __restrict_
     }
 }
 
-// the two scalar corrections of the zero-knowledge quotient: h[0] -= sub0, h[top_index] = top
+// the two scalar corrections of the zero-knowledge quotient: h[0] -= sub0, h[top_index] = top (top_index = ~0: the caller
+// appends the top coefficient itself -- the sharded pipeline, whose coefficient N lies outside every shard's block)
 template <class F>
 __global__ void k_h_fix(uint4* __restrict__ h, u64 top_index, FeArg sub0, FeArg top) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         fe_store(h, fe_sub<F>(fe_load(h), fe_from_arg(sub0)));
-        fe_store(h + 2 * top_index, fe_from_arg(top));
+        if (top_index != ~0ull) fe_store(h + 2 * top_index, fe_from_arg(top));
     }
 }
 

@@ -16,9 +16,11 @@
 //     order is chosen (logical index v = bitrev(u)) so that the FIRST exchange is the one that
 //     crosses wavefronts (LDS + s_barrier) and every later one stays inside a wavefront: those
 //     go through a wave-private LDS window with no barrier at all (DS operations of one wave
-//     execute in order) -- or, with ACX_NTT_XCHG=dpp, through v_permlane32_swap /
-//     v_permlane16_swap / DPP row rotations without touching LDS ("wavefront-shuffle
-//     butterflies").  With v = bitrev(u) a contiguous input row is also read in lane order.
+//     execute in order): the wavefront shuffle of the butterflies.  (A flavour on v_permlane32_swap /
+//     v_permlane16_swap / DPP row rotations with no LDS at all was built and measured in round 2:
+//     bit-exact, 0-3 % slower at every size because it spends VALU issue slots in a VALU-bound kernel;
+//     profiles/r02_ntt.txt sections 3-4, code in git history before round 3.)  With v = bitrev(u) a
+//     contiguous input row is also read in lane order.
 //   * XOR-swizzled LDS addresses make both sides of every exchange bank-conflict free.
 #pragma once
 #include "kernels.hip.h"
@@ -45,39 +47,6 @@ __device__ __forceinline__ Fe fe_reduce_loose(Fe a) {
     }
     // r in [0, 3p) here (q may be one short of the exact quotient): bring it below 2p
     return fe_cond_sub<F::P2>(r);
-}
-
-enum NttXchg { kXchgLds = 0, kXchgDpp = 1 };
-
-// ---- intra-wave exchange without LDS ---------------------------------------------------------------
-// Swap registers between lanes that differ in ONE lane bit: lanes with the bit clear give `hi` and
-// receive the partner's `lo`; lanes with the bit set give `lo` and receive the partner's `hi`.
-// (After it, `lo` of a clear lane and `hi`... are unchanged; see xchg_dpp.)
-template <int BIT>
-__device__ __forceinline__ void lane_swap(u32& lo, u32& hi) {
-    if constexpr (BIT == 5) {
-        // v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src
-        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
-        lo = r[0]; hi = r[1];
-    } else if constexpr (BIT == 4) {
-        // v_permlane16_swap vdst, src: odd rows of vdst <-> even rows of src
-        const auto r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
-        lo = r[0]; hi = r[1];
-    } else {
-        // DPP inside a row of 16 lanes.  send = what this lane gives away, got = partner's gift.
-        const bool set = (threadIdx.x >> BIT) & 1u;
-        const u32 send = set ? lo : hi;
-        u32 got;
-        if constexpr (BIT == 0) got = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
-        else if constexpr (BIT == 1) got = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-        else if constexpr (BIT == 3) got = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xF, 0xF, true); // row_ror:8
-        else {                                                                                                     // BIT == 2: lane ^ 4
-            const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x124, 0xF, 0xF, true);   // row_ror:4  -> from lane - 4
-            const u32 dn = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x12C, 0xF, 0xF, true);   // row_ror:12 -> from lane + 4
-            got = set ? up : dn;
-        }
-        if (set) lo = got; else hi = got;
-    }
 }
 
 // sub-transform twiddles in limb form: entry j = 3 x uint4 = the nine 29-bit limbs of w_S^j (strict) + padding
@@ -120,30 +89,18 @@ __device__ __forceinline__ void r4_round(Fe (&x)[4], const uint4* __restrict__ t
     }
 }
 
-// 4x4 transpose between the four lanes of an in-wave field at physical bits (PHI+1, PHI) without LDS:
-// logical slot bit 0 <-> lane bit PHI+1, slot bit 1 <-> lane bit PHI.
-template <int PHI>
-__device__ __forceinline__ void r4_xchg_dpp(Fe (&x)[4]) {
-#pragma unroll
-    for (int k = 0; k < kLimbs; ++k) {
-        lane_swap<PHI + 1>(x[0].l[k], x[1].l[k]); lane_swap<PHI + 1>(x[2].l[k], x[3].l[k]);
-        lane_swap<PHI>(x[0].l[k], x[2].l[k]);     lane_swap<PHI>(x[1].l[k], x[3].l[k]);
-    }
-}
-
 // ---- the pass kernel ---------------------------------------------------------------------------------
 // LP: even number of extended position bits of a thread group (sub-transform digit rounded up to
 // even); LG: log2(thread groups per workgroup).  blockDim.x = 2^(LP-2+LG), tile = 2^(LP+LG) elements.
 // The rounds are a real loop (one body in the instruction cache, ~1.5k instructions, instead of a
 // 12k-instruction straight line), and so are the four closing multiplications (slots rotate through x[0]).
-template <class F, int LP, int LG, int XCHG>
+template <class F, int LP, int LG>
 __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
     constexpr int LU = LP - 2;
     constexpr u32 U = 1u << LU;
     constexpr int R = LP / 2;
     constexpr u32 ELEMS = 4u << (LU + LG);
-    // an exchange needs LDS when it crosses wavefronts, or always in the LDS flavour
-    constexpr bool kUsesLds = (XCHG == kXchgLds && R > 1) || (LU > 6);
+    constexpr bool kUsesLds = R > 1;          // a single round exchanges nothing
     __shared__ u32 lds[kUsesLds ? kLimbs : 1][kUsesLds ? ELEMS : 1];
 
     const u32 ls = P.log_s;                  // LP == ls (even digit) or ls + 1 (odd digit: two columns per group)
@@ -219,11 +176,7 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
         // exchange: slot digit <-> lane field at physical bits (phi+1, phi)
         const int phi = LP - 2 - 2 * r;
         const bool cross = phi > 4;
-        if (XCHG == kXchgDpp && !cross) {
-            if (phi == 4) r4_xchg_dpp<4>(x);
-            else if (phi == 2) r4_xchg_dpp<2>(x);
-            else r4_xchg_dpp<0>(x);
-        } else {
+        {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const u32 a = gbase + (u32)e * U + (u ^ (rev2(e) << phi));

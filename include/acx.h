@@ -321,6 +321,63 @@ int acx_batch_create(acx_ctx* ctx, uint64_t count, acx_r1cs* const* systems, con
 int acx_batch_verify_dev(acx_batch* batch);
 void acx_batch_destroy(acx_batch* batch);
 
+/* ---------------------------------------------------------------- one process, several GPUs
+ * The reference's callers make ONE pure call from one thread -- `verifyAssignment qap assignment` (src/QAP.hs:276-282),
+ * `all (verifyAssignment qap . generateAssignment program) inputs` (test/Test/Circuit/Arithmetic.hs:200-209),
+ * `verificationWitness` (src/QAP.hs:292-327) -- so a drop-in host reaches the GPUs of a node through THIS handle, with the
+ * same call shapes as the single-GPU entry points and nothing else to bind: the library shards the constraint rows over the
+ * devices (block-cyclic, SURVEY.md 8e: shard g owns the rows k with (k mod R) in block g of R / n_devices, N = R * C), replicates
+ * the witness (one host-to-device copy per GPU), and issues the collectives itself over RCCL: ONE ncclAllReduce for the
+ * verdict of a check, ONE ncclAllToAll per transform (six per h(x)), overlapped with the local steps on a second stream per GPU.
+ * BASELINE.json configs[3] (2^24 constraints over 8 GPUs) is `acx_mgpu_create(field, {0..7}, 8, &mg)` + the calls below.
+ *
+ * device_ids: n_devices (a power of two, <= 64) HIP device ordinals.  Distinct ids: RCCL (bound with dlopen here, so a
+ * single-GPU user of libacx never maps it); ACX_MGPU_TRANSPORT=peer selects hipMemcpyPeerAsync copies and a host-side sum
+ * instead (DMA engines over xGMI, no collective kernels).  A list with REPEATED ids places several shards on one GPU --
+ * which RCCL cannot do, so the peer-copy transport is used: the n_devices = 2 / 4 / 8 paths on a one-GPU machine.
+ * Results never depend on n_devices or the transport: every output below is bit-identical to the single-GPU call.
+ *
+ * Systems below the shard threshold (N < 2^14 by default, acx_mgpu_set_shard_threshold; never below 2^10 nor above 2^24
+ * for h(x), 2 n_devices <= sqrt(N)) are held whole on the first device and every call on them is the single-GPU one.
+ * acx_mgpu_* calls on one handle are serialised (the collectives are ordered); different handles are independent. */
+typedef struct acx_mgpu acx_mgpu;
+typedef struct acx_mgpu_r1cs acx_mgpu_r1cs;
+enum { ACX_MGPU_RCCL = 0, ACX_MGPU_PEER_COPY = 1 };
+
+/* replaces acx_ctx_create for a multi-GPU host (SURVEY.md 8b proposed `device_ids[], n_devices`) */
+int acx_mgpu_create(int field, const int* device_ids, uint32_t n_devices, acx_mgpu** out);
+void acx_mgpu_destroy(acx_mgpu* mg);
+int acx_mgpu_info(const acx_mgpu* mg, uint32_t* n_devices, int* transport, uint32_t* shard_threshold_log_n);
+/* the context of one shard (its device, stream, root table): acx_ctx_root_of_unity, acx_ctx_stream for event timing */
+acx_ctx* acx_mgpu_ctx(acx_mgpu* mg, uint32_t shard);
+int acx_mgpu_set_shard_threshold(acx_mgpu* mg, uint32_t log_n);
+int acx_mgpu_set_root(acx_mgpu* mg, uint32_t two_adicity, const acx_fr* omega);      /* acx_ctx_set_root on every shard */
+int acx_mgpu_sync(acx_mgpu* mg);
+
+/* acx_r1cs_load / acx_circuit_to_r1cs (`arithCircuitToGenQAP`, src/QAP.hs:530-539) with the rows sharded over the devices:
+ * each shard's rows are gathered and uploaded by its own host thread; no device ever holds the whole system. */
+int acx_mgpu_r1cs_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C,
+                       acx_mgpu_r1cs** out);
+int acx_mgpu_circuit_to_r1cs(acx_mgpu* mg, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_mgpu_r1cs** out);
+void acx_mgpu_r1cs_destroy(acx_mgpu_r1cs* r);
+int acx_mgpu_r1cs_dims(const acx_mgpu_r1cs* r, uint64_t* n, uint64_t* m, uint32_t* log_n, uint32_t* n_shards);
+
+/* `verifyAssignment` (src/QAP.hs:276-282) over all devices: arguments and results of acx_r1cs_verify (first_bad = the smallest
+ * violated GLOBAL row; passing NULL saves the second all-reduce of a failing check). */
+int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad);
+/* `verificationWitnessZk` (src/QAP.hs:300-327) over all devices: arguments and results of acx_qap_h (out_h holds N + 1 elements). */
+int acx_mgpu_qap_h(acx_mgpu_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok);
+/* `FFT.fft` / `FFT.interpolate` (galois-fft; src/QAP.hs:521-524) of ONE 2^log_n-point vector spread over the devices: host data
+ * in natural order in and out, arguments of acx_ntt with batch = 1. */
+int acx_mgpu_ntt(acx_mgpu* mg, uint32_t log_n, int inverse, const acx_fr* shift, const acx_fr* in, acx_fr* out);
+
+/* The same with the witness already resident (sharded systems only): upload once, verify / compute h(x) many times; h(x)
+ * stays on the devices (COLS ownership) until it is fetched.  What bench.py times: inputs in HBM when the clock starts. */
+int acx_mgpu_witness_upload(acx_mgpu_r1cs* r, const acx_fr* witness);
+int acx_mgpu_r1cs_verify_resident(acx_mgpu_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* first_bad);
+int acx_mgpu_qap_h_resident(acx_mgpu_r1cs* r, const acx_fr* delta, int* ok);
+int acx_mgpu_qap_h_fetch(acx_mgpu_r1cs* r, acx_fr* out_h, uint64_t* h_len);
+
 #ifdef __cplusplus
 }
 #endif

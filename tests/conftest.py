@@ -24,13 +24,28 @@ def acx():
     return _load_acx()
 
 
+_GPU_REQUIRED = False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest -m gpu` (the GPU job: the marker expression selects gpu tests and does not negate them) REQUIRES a GPU:
+    a box that has lost its device must fail, not skip its way to green.  ACX_REQUIRE_GPU=1 forces the same."""
+    global _GPU_REQUIRED
+    expr = (config.option.markexpr or "").replace(" ", "")
+    _GPU_REQUIRED = os.environ.get("ACX_REQUIRE_GPU") == "1" or ("gpu" in expr and "notgpu" not in expr)
+
+
+def gpu_required() -> bool:
+    return _GPU_REQUIRED
+
+
 def _gpu_context(acx, field):
-    """GPU context.  On a box with no GPU at all the GPU tests SKIP (so that a plain `pytest tests` is green
-    there); wherever a GPU is visible -- the driver's GPU box -- or with ACX_REQUIRE_GPU=1, a failure to create the
-    context is an error: there is no CPU path to fall into."""
+    """GPU context.  A plain `pytest tests` on a box with no GPU SKIPS the GPU tests; under `-m gpu` or with
+    ACX_REQUIRE_GPU=1, and wherever a GPU is visible, a failure to create the context is an error: there is no CPU
+    path to fall into."""
     import torch
-    if not torch.cuda.is_available() and os.environ.get("ACX_REQUIRE_GPU") != "1":
-        pytest.skip("no GPU visible (set ACX_REQUIRE_GPU=1 to make this an error)")
+    if not torch.cuda.is_available() and not _GPU_REQUIRED:
+        pytest.skip("no GPU visible (run with -m gpu or ACX_REQUIRE_GPU=1 to make this an error)")
     return acx.Context(field, 0)
 
 

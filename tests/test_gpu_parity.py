@@ -17,9 +17,12 @@ FIELDS = {"bn254": R.BN254, "bls12_381": R.BLS12_381}
 
 def _need_gpu():
     """Subprocess-based GPU tests have no context fixture: apply the fixtures' rule (tests/conftest.py)."""
-    import os, torch
-    if not torch.cuda.is_available() and os.environ.get("ACX_REQUIRE_GPU") != "1":
-        pytest.skip("no GPU visible (set ACX_REQUIRE_GPU=1 to make this an error)")
+    import torch
+    from tests.conftest import gpu_required
+    if not torch.cuda.is_available():
+        if gpu_required():
+            pytest.fail("no GPU visible and the run requires one (-m gpu / ACX_REQUIRE_GPU=1)")
+        pytest.skip("no GPU visible (run with -m gpu or ACX_REQUIRE_GPU=1 to make this an error)")
 
 
 def _ctx(request, field):
@@ -1244,15 +1247,14 @@ def test_small_coefficient_mulgraph_h_and_columns(request, acx, field):
 
 
 @pytest.mark.gpu
-def test_one_wave_per_slice_kernel_stays_bit_exact():
-    """k_r1cs_sell (one wave per slice) is kept beside the wave-specialised default for A/B measurements
-    (ACX_SELL_SPLIT=0): the differential fuzz against the C oracle -- random shapes, all three matrix forms, long rows,
-    both fields -- must pass on it too."""
+def test_differential_fuzz_r1cs():
+    """tools/fuzz_r1cs.py: the residual kernels against the C oracle on random shapes -- all three matrix forms, long rows,
+    both fields, corrupted witnesses."""
     _need_gpu()
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_r1cs.py"), "25"], cwd=root,
-                         env=dict(os.environ, ACX_SELL_SPLIT="0"), capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 

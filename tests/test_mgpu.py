@@ -1,0 +1,177 @@
+"""acx_mgpu_*: the N-GPU path behind the C ABI (include/acx.h; one process, the library shards the rows and issues the
+collectives).  Every result must be bit-identical to the single-GPU entry point and to the C oracle:
+
+  * devices = [0]                     one shard through the REAL RCCL calls (ncclCommInitAll, ncclAllToAll, ncclAllReduce)
+  * devices = [0, 0] / [0] * 4 / * 8  several shards on the one GPU of the box, exchanged by device copies: the W > 1
+                                      ownership, exchange and gather logic
+`verifyAssignment` (/root/reference/src/QAP.hs:276-282), `verificationWitness[Zk]` (src/QAP.hs:292-327) and the
+transform behind `createPolynomialsFFT` (src/QAP.hs:512-525) each in its one-call shape."""
+import numpy as np
+import pytest
+
+from oracle import ref_qap as R
+
+pytestmark = pytest.mark.gpu
+U64_MAX = 2**64 - 1
+
+
+def _mg(acx, request, field, devices):
+    from tests.conftest import gpu_required
+    import torch
+    if not torch.cuda.is_available():
+        if gpu_required():
+            pytest.fail("no GPU visible and the run requires one")
+        pytest.skip("no GPU visible")
+    mg = acx.MultiGpu(field, devices)
+    request.addfinalizer(mg.close)
+    return mg
+
+
+def _orc(request, field):
+    return request.getfixturevalue("c_oracle_bn254" if field == "bn254" else "c_oracle_bls")
+
+
+DEVICE_LISTS = [[0], [0, 0], [0, 0, 0, 0], [0] * 8]
+
+
+@pytest.mark.parametrize("devices", DEVICE_LISTS, ids=lambda d: f"W{len(d)}")
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+def test_mgpu_verify_and_h_equal_single_gpu_and_oracle(acx, request, field, devices):
+    synth = acx.synth
+    mg = _mg(acx, request, field, devices)
+    assert mg.transport == ("rccl" if len(devices) == 1 else "peer-copy")
+    mg.set_shard_threshold(10)
+    orc = _orc(request, field)
+    n = (1 << 13) - 37                                        # padding rows in every shard
+    s = synth.mulgraph(n, n_in=64, window=512, seed=0xA11CE + len(devices), field=field)
+    mats, w = s.rows(), s.witness()
+    mr = mg.from_circuit(s.circuit)
+    assert (mr.n, mr.m, mr.log_n, mr.n_shards) == (n, s.circuit.m, 13, len(devices))
+    assert mr.verify(w) == (True, 0, U64_MAX)
+    h, ok = mr.qap_h(w)
+    want_h, want_ok = orc.qap_h(n, mr.m, 13, *mats, w)
+    assert ok and want_ok
+    assert np.array_equal(h, want_h[: h.shape[0]]) and not want_h[h.shape[0]:].any()
+    # a corrupted witness: count and smallest violated GLOBAL row as the oracle reports them, h = Nothing
+    bad = w.copy()
+    bad[s.circuit.m // 2, 0] ^= np.uint64(1)
+    _, nbad, first = orc.r1cs_residuals(n, mr.m, *mats, bad)
+    assert nbad > 0
+    assert mr.verify(bad) == (False, nbad, first)
+    assert mr.verify(bad, want_first=False) == (False, nbad, U64_MAX)
+    assert mr.qap_h(bad) == (None, False)
+    # the zero-knowledge quotient (src/QAP.hs:300-327)
+    p = R.BN254.p if field == "bn254" else R.BLS12_381.p
+    delta = [3, p - 5, 1234567]
+    hz, okz = mr.qap_h(w, delta)
+    ctx1 = request.getfixturevalue("ctx_bn254" if field == "bn254" else "ctx_bls")
+    r1 = s.circuit.to_r1cs(ctx1)
+    hz1, okz1 = r1.qap_h(w, delta)
+    assert okz and okz1 and np.array_equal(hz, hz1)
+    # resident form: upload once, verify / h many times
+    mr.upload_witness(w)
+    assert mr.verify_resident() == (True, 0, U64_MAX)
+    assert mr.qap_h_resident()
+    assert np.array_equal(mr.qap_h_fetch(), h)
+    r1.close()
+    mr.close()
+
+
+@pytest.mark.parametrize("devices", DEVICE_LISTS, ids=lambda d: f"W{len(d)}")
+def test_mgpu_ntt_matches_single_gpu(acx, request, devices):
+    """One vector spread over the shards (natural order in and out): forward, inverse, coset, odd and even sizes."""
+    synth = acx.synth
+    mg = _mg(acx, request, "bn254", devices)
+    ctx1 = request.getfixturevalue("ctx_bn254")
+    for log_n in (10, 13, 16):
+        if 2 * len(devices) > (1 << (log_n // 2)):
+            continue
+        x = synth.random_fr(1 << log_n, 77 + log_n, 1)
+        for inverse in (False, True):
+            for shift in (None, 5):
+                got = mg.ntt(x, log_n, inverse=inverse, shift=shift)
+                want = ctx1.ntt(x, log_n, inverse=inverse, shift=shift)
+                assert np.array_equal(got, want), (log_n, inverse, shift)
+    # a non-canonical element is an error, as at every host edge
+    x = synth.random_fr(1 << 10, 3, 1)
+    x[5] = np.array([U64_MAX] * 4, dtype=np.uint64)
+    with pytest.raises(acx.AcxError) as e:
+        mg.ntt(x, 10)
+    assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
+
+
+def test_mgpu_small_system_stays_whole(acx, request):
+    """Below the shard threshold the system lives on the first device and every call is the single-GPU one (the
+    reference's own test sizes)."""
+    import random
+    from tests import helpers as H
+    mg = _mg(acx, request, "bn254", [0, 0])
+    p = R.BN254.p
+    rnd = random.Random(99)
+    gates = H.arb_arith_circuit(rnd, p, 3, 20)
+    host = H.to_acx_circuit(acx, gates).marshal("bn254")
+    mr = mg.from_circuit(host)
+    assert mr.n_shards == 1
+    inputs = acx.ints_to_fr([rnd.randrange(p) for _ in range(3)])
+    w, _ = host.eval(inputs)
+    assert mr.verify(w)[0]
+    mr.close()
+
+
+def test_mgpu_sharded_gate_mix_long_rows(acx, request):
+    """A circuit in the reference's gate mix (Mul : Equal : Split, test/Test/Circuit/Arithmetic.hs:136; the 257-entry rows of
+    its Split gates take the CSR kernel) sharded over four shards: verdict, first violated row and h(x) against the oracle."""
+    import random
+    from tests import helpers as H
+    mg = _mg(acx, request, "bn254", [0, 0, 0, 0])
+    mg.set_shard_threshold(10)
+    orc = _orc(request, "bn254")
+    p = R.BN254.p
+    rnd = random.Random(4242)
+    gates = H.arb_arith_circuit(rnd, p, 4, 260, dist=(50, 10, 2))
+    host = H.to_acx_circuit(acx, gates).marshal("bn254")
+    mats = host.rows()
+    inputs = acx.ints_to_fr([rnd.randrange(p) for _ in range(4)])
+    w, _ = host.eval(inputs)
+    mr = mg.from_circuit(host)
+    assert mr.n_shards == 4
+    assert mr.verify(w) == (True, 0, U64_MAX)
+    h, ok = mr.qap_h(w)
+    want_h, _ = orc.qap_h(mr.n, mr.m, mr.log_n, *mats, w)
+    assert ok and np.array_equal(h, want_h[: h.shape[0]]) and not want_h[h.shape[0]:].any()
+    bad = w.copy()
+    bad[1 + 4 + 7, 0] ^= np.uint64(2)
+    _, nbad, first = orc.r1cs_residuals(mr.n, mr.m, *mats, bad)
+    assert mr.verify(bad) == (False, nbad, first)
+    mr.close()
+
+
+def test_mgpu_argument_errors(acx, request):
+    import ctypes as C
+    lib = acx._lib.load()
+    h = C.c_void_p()
+    ids3 = (C.c_int * 3)(0, 0, 0)
+    assert lib.acx_mgpu_create(0, ids3, 3, C.byref(h)) == acx._lib.STATUS["INVALID_ARG"]        # not a power of two
+    assert lib.acx_mgpu_create(0, None, 1, C.byref(h)) == acx._lib.STATUS["INVALID_ARG"]
+    bad = (C.c_int * 1)(4096)
+    assert lib.acx_mgpu_create(0, bad, 1, C.byref(h)) == acx._lib.STATUS["NO_DEVICE"]
+    mg = _mg(acx, request, "bn254", [0])
+    s = acx.synth.mulgraph(1 << 10, n_in=16, window=64)
+    mr = mg.from_circuit(s.circuit)                       # 2^10 < threshold 2^14: whole on shard 0
+    assert mr.n_shards == 1
+    with pytest.raises(acx.AcxError) as e:
+        mr.upload_witness(s.witness())
+    assert e.value.status == acx._lib.STATUS["UNSUPPORTED"]
+    w = s.witness()
+    assert mr.verify(w) == (True, 0, U64_MAX)
+    h1, ok = mr.qap_h(w)
+    assert ok and h1 is not None
+    w[3] = np.array([U64_MAX] * 4, dtype=np.uint64)
+    mg.set_shard_threshold(10)
+    mr2 = mg.from_circuit(s.circuit)
+    assert mr2.n_shards == 1 and mr2.log_n == 10
+    with pytest.raises(acx.AcxError) as e:
+        mr2.verify(w)
+    assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
+    mr.close()
+    mr2.close()

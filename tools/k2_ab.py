@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of K2 variants on the bench workload in ONE process run each, alternating: python tools/k2_ab.py 0 1 2  (values of
-ACX_K2_VARIANT; 'old' = ACX_SELL_SPLIT=0).  Prints kernel us per launch of bench.py --no-cpu --no-ntt for every variant, three rounds."""
+ACX_K2_MULTI, or paths of other builds of libacx.so -> ACX_LIB).  Prints kernel us per launch of bench.py --no-cpu --no-ntt for every variant, three rounds."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 variants = sys.argv[1:] or ["0"]
@@ -8,9 +8,7 @@ res = {v: [] for v in variants}
 for rnd in range(3):
     for v in variants:
         env = dict(os.environ)
-        if v == "old":
-            env["ACX_SELL_SPLIT"] = "0"
-        elif v.endswith(".so"):
+        if v.endswith(".so"):
             env["ACX_LIB"] = os.path.abspath(v)         # another build of the library (A/B of two source states on one box)
         else:
             env["ACX_K2_MULTI"] = v
