@@ -102,8 +102,10 @@ SYMBOLS = {
     "acx_mgpu_set_shard_threshold": (_I, [_P, _U32]),
     "acx_mgpu_set_root": (_I, [_P, _U32, _P]),
     "acx_mgpu_sync": (_I, [_P]),
-    "acx_mgpu_r1cs_load": (_I, [_P, _U64, _U64, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), C.POINTER(_P)]),
-    "acx_mgpu_circuit_to_r1cs": (_I, [_P, _P, _P, _U64, C.POINTER(_P)]),
+    "acx_mgpu_r1cs_load": (_I, [_P, _U64, _U64, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), _U32, C.POINTER(_P)]),
+    "acx_mgpu_circuit_to_r1cs": (_I, [_P, _P, _P, _U64, _U32, C.POINTER(_P)]),
+    "acx_mgpu_r1cs_verify_enqueue": (_I, [_P, _U32]),
+    "acx_mgpu_r1cs_verdicts": (_I, [_P, _U32, _U32, _P]),
     "acx_mgpu_r1cs_destroy": (None, [_P]),
     "acx_mgpu_r1cs_dims": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U32), C.POINTER(_U32)]),
     "acx_mgpu_r1cs_verify": (_I, [_P, _P, C.POINTER(_I), C.POINTER(_U64), C.POINTER(_U64)]),

@@ -5,9 +5,13 @@
 // (test/Test/Circuit/Arithmetic.hs:200-209), `verificationWitness` (src/QAP.hs:292-327) -- so the sharding over the GPUs
 // of a node and the collectives between them live HERE, under the header, not in the host program:
 //
-//   rows          block-cyclic: with N = 2^log_n = R * C, shard g owns the rows k = k1 + k2 R with k1 in block g
-//                 of R/W, stored in ROWS order [kl][k2] -- so its residual kernel's <A_i,w>, <B_i,w>, <C_i,w> ARE three
-//                 evaluation vectors in the layout the first inverse transform reads.  Rows >= n are empty rows.
+//   rows          TWO ownerships per system (288 GB of HBM per GPU: memory is not what is scarce).  For verifyAssignment:
+//                 contiguous slabs balanced by nnz -- the rows in flight on a GPU gather from one narrow
+//                 window of the witness, which is worth 1.5-2x on the residual kernel (profiles/r02_dist_budget.txt).  For
+//                 h(x): block-cyclic -- with N = 2^log_n = R * C, shard g owns the rows k = k1 + k2 R with k1 in block g of R/W,
+//                 stored in ROWS order [kl][k2], so its residual kernel's <A_i,w>, <B_i,w>, <C_i,w> ARE three evaluation
+//                 vectors in the layout the first inverse transform reads (rows >= n are empty rows).
+//                 ACX_MGPU_VERIFY_ONLY at load time skips the second copy.
 //   witness       replicated: one host-to-device copy per GPU (each over its own PCIe link, one host thread each)
 //   verdict       ONE ncclAllReduce (sum of the violated-row counts); a second one (min) only for first_bad of a failing check
 //   transforms    four-step, one launch per local step (ntt_dist_step_locked) and ONE ncclAllToAll between the two steps, issued
@@ -96,6 +100,7 @@ static const RcclApi* rccl_api(std::string& why) {
     } while (0)
 
 constexpr int kMgSlots = 3;          // transforms in flight (the three vectors of h(x))
+constexpr uint32_t kMgRing = 16;     // result slots of acx_mgpu_r1cs_verify_enqueue
 
 struct MgSlot {                      // one exchange buffer pair of one shard
     uint4 *send = nullptr, *recv = nullptr;
@@ -137,11 +142,15 @@ struct acx_mgpu_r1cs {
     bool sharded = false;
     acx_r1cs* whole = nullptr;                      // !sharded: the whole system on shard 0
     struct Part {
-        acx_r1cs* r = nullptr;                      // this shard's N/W rows in ROWS order
+        acx_r1cs* slab = nullptr;                   // rows [row0, row0 + slab->n): what verifyAssignment runs on
+        uint64_t row0 = 0;
+        acx_r1cs* cyc = nullptr;                    // this shard's N/W block-cyclic rows in ROWS order: what h(x) runs on (null: verify only)
         uint4* d_w = nullptr;                       // the replicated witness, m dev elements
         uint4* vec = nullptr;                       // h(x) pipeline: dots 3L | coef 3L | pw L | h L (allocated on first use)
+        unsigned long long* ring = nullptr;         // kMgRing result slots {n_bad, first_bad} of the asynchronous form + their reduction
     };
     std::vector<Part> part;
+    bool has_cyclic = false;
     bool witness_resident = false;
     bool h_valid = false;                           // part[].vec holds h of the resident witness (acx_mgpu_qap_h_fetch)
     H256 h_top{{0, 0, 0, 0}};                       // coefficient N of the zero-knowledge quotient (d1 d2), Montgomery
@@ -349,8 +358,11 @@ int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_
         CtxLock lock(S.ctx->mu);
         static const unsigned long long init[2] = {0ull, ~0ull};
         HIP_TRY(hipMemcpyAsync(S.d_res, init, 16, hipMemcpyHostToDevice, S.ctx->stream));      // the canonicity flag stays
-        ACX_TRY(launch_residual(mr->part[s].r, mr->part[s].d_w, (uint64_t)s * rw, S.d_res, nullptr, with_dots ? mr->part[s].vec : nullptr, L,
-                                log_c, mr->log_r));
+        const auto& P = mr->part[s];
+        if (with_dots)          // the block-cyclic copy: dots in ROWS layout, first_bad through the cyclic row map
+            ACX_TRY(launch_residual(P.cyc, P.d_w, (uint64_t)s * rw, S.d_res, nullptr, P.vec, L, log_c, mr->log_r));
+        else
+            ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, S.d_res, nullptr, nullptr, 0));
     }
     CallSlot slot0;
     unsigned long long total = 0, first = ~0ull;
@@ -516,16 +528,35 @@ void mg_free_r1cs(acx_mgpu_r1cs* mr) {
     if (mr->whole) acx_r1cs_destroy(mr->whole);
     for (size_t s = 0; s < mr->part.size(); ++s) {
         auto& p = mr->part[s];
-        if (p.r) acx_r1cs_destroy(p.r);                               // synchronises that device
+        if (p.slab) acx_r1cs_destroy(p.slab);                         // synchronises that device
+        if (p.cyc) acx_r1cs_destroy(p.cyc);
         (void)hipSetDevice(mg->sh[s].device);
         if (p.d_w) (void)hipFree(p.d_w);
         if (p.vec) (void)hipFree(p.vec);
+        if (p.ring) (void)hipFree(p.ring);
     }
     delete mr;
 }
 
-int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], acx_mgpu_r1cs** out) {
+// contiguous slabs balanced by nnz(A) + nnz(B) + nnz(C) + 1 per row (Split gates make 257-row bursts of uneven cost,
+// test/Test/Circuit/Arithmetic.hs:123): W + 1 boundaries
+std::vector<uint64_t> mg_slab_bounds(const acx_csr* const mats[3], uint64_t n, uint32_t W) {
+    auto cost = [&](uint64_t i) { return (uint64_t)mats[0]->rowptr[i] + mats[1]->rowptr[i] + mats[2]->rowptr[i] + i; };
+    const uint64_t total = cost(n);
+    std::vector<uint64_t> b(W + 1, n);
+    b[0] = 0;
+    for (uint32_t r = 1; r < W; ++r) {
+        const uint64_t want = total / W * r;
+        uint64_t lo = b[r - 1], hi = n;
+        while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (cost(mid) < want) lo = mid + 1; else hi = mid; }
+        b[r] = lo;
+    }
+    return b;
+}
+
+int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], uint32_t flags, acx_mgpu_r1cs** out) {
     if (m == 0 || m >= 0xffffffffull || n >= 0xffffffffull) return fail(ACX_ERR_TOO_LARGE, "n or m out of range");
+    if (flags & ~(uint32_t)ACX_MGPU_VERIFY_ONLY) return fail(ACX_ERR_INVALID_ARG, "unknown load flag");
     const uint32_t log_n = ceil_log2(std::max<uint64_t>(n, 1));
     if ((int)log_n > mg->sh[0].ctx->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "n exceeds 2^two_adicity");
     for (int k = 0; k < 3; ++k) {
@@ -538,30 +569,55 @@ int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], 
     std::unique_ptr<acx_mgpu_r1cs> mr(new acx_mgpu_r1cs());
     mr->mg = mg; mr->n = n; mr->m = m; mr->log_n = log_n;
     const uint32_t W = mg->W;
-    // verification alone would shard at any size; the transforms of h(x) need mg_can_distribute.  Above 2^24 rows the
-    // row ownership keeps R = 2^12 (verification only: acx_mgpu_qap_h reports ACX_ERR_UNSUPPORTED there).
-    mr->sharded = W > 1 ? (log_n >= mg->min_log_n && (mg_can_distribute(W, log_n) || log_n > 24))
-                        : (log_n >= mg->min_log_n && mg_can_distribute(1, log_n));
+    // One shard is "sharded" too when the size allows the four-step transform (its exchange is RCCL's all-to-all with itself):
+    // the same code path at every n_devices.  Several shards split any system at or above the threshold; the block-cyclic
+    // copy for h(x) exists where the transforms can be distributed (mg_can_distribute).
+    const bool can_h = mg_can_distribute(W, log_n);
+    mr->sharded = log_n >= mg->min_log_n && (W > 1 || can_h);
     if (!mr->sharded) {
         ACX_TRY(r1cs_from_host(mg->sh[0].ctx, n, m, mats, &mr->whole));
         *out = mr.release();
         return ACX_OK;
     }
-    mr->log_r = log_n > 24 ? 12 : log_n / 2;
+    mr->has_cyclic = can_h && !(flags & ACX_MGPU_VERIFY_ONLY);
+    mr->log_r = log_n / 2;
     mr->part.resize(W);
     const uint64_t L = (1ull << log_n) / W;
+    const std::vector<uint64_t> bounds = mg_slab_bounds(mats, n, W);
     const int rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
-        ShardRows rows[3];
-        acx_csr views[3];
-        const acx_csr* mp[3];
-        for (int k = 0; k < 3; ++k) {
-            mg_gather_rows(*mats[k], n, log_n, mr->log_r, W, s, rows[k]);
-            views[k] = acx_csr{rows[k].rowptr.data(), rows[k].col.data(), rows[k].val.data()};
-            mp[k] = &views[k];
-        }
-        ACX_TRY(r1cs_from_host(mg->sh[s].ctx, L, m, mp, &mr->part[s].r));
+        auto& P = mr->part[s];
         HIP_TRY(hipSetDevice(mg->sh[s].device));
-        HIP_TRY(hipMalloc((void**)&mr->part[s].d_w, m * 32));
+        {   // the slab: views into the caller's arrays, row pointers rebased
+            const uint64_t b0 = bounds[s], b1 = bounds[s + 1];
+            std::vector<uint32_t> rp[3];
+            acx_csr views[3];
+            const acx_csr* mp[3];
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t e0 = mats[k]->rowptr[b0];
+                rp[k].resize(b1 - b0 + 1);
+                for (uint64_t i = b0; i <= b1; ++i) rp[k][i - b0] = mats[k]->rowptr[i] - e0;
+                views[k] = acx_csr{rp[k].data(), mats[k]->col ? mats[k]->col + e0 : nullptr, mats[k]->val ? mats[k]->val + e0 : nullptr};
+                mp[k] = &views[k];
+            }
+            P.row0 = b0;
+            ACX_TRY(r1cs_from_host(mg->sh[s].ctx, b1 - b0, m, mp, &P.slab));
+        }
+        if (mr->has_cyclic) {
+            ShardRows rows[3];
+            acx_csr views[3];
+            const acx_csr* mp[3];
+            for (int k = 0; k < 3; ++k) {
+                mg_gather_rows(*mats[k], n, log_n, mr->log_r, W, s, rows[k]);
+                views[k] = acx_csr{rows[k].rowptr.data(), rows[k].col.data(), rows[k].val.data()};
+                mp[k] = &views[k];
+            }
+            ACX_TRY(r1cs_from_host(mg->sh[s].ctx, L, m, mp, &P.cyc));
+        }
+        HIP_TRY(hipMalloc((void**)&P.d_w, m * 32));
+        HIP_TRY(hipMalloc((void**)&P.ring, 2 * 2 * kMgRing * 8));
+        std::vector<unsigned long long> init(2 * 2 * kMgRing);
+        for (uint32_t i = 0; i < 2 * kMgRing; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
+        HIP_TRY(hipMemcpy(P.ring, init.data(), init.size() * 8, hipMemcpyHostToDevice));
         return ACX_OK;
     });
     if (rc != ACX_OK) { mg_free_r1cs(mr.release()); return rc; }
@@ -574,7 +630,8 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
     acx_mgpu* mg = mr->mg;
     const uint32_t W = mg->W;
     const HostField& hf = mg->sh[0].ctx->hf;
-    if (!mg_can_distribute(W, mr->log_n)) return fail(ACX_ERR_UNSUPPORTED, "distributed h(x) needs 2^10 <= N <= 2^24 and 2 W <= sqrt(N)");
+    if (!mr->has_cyclic)
+        return fail(ACX_ERR_UNSUPPORTED, "no block-cyclic copy of this system: loaded with ACX_MGPU_VERIFY_ONLY, or N outside 2^10 .. 2^24 / 2 W > sqrt(N)");
     if ((int)mr->log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
     const uint64_t N = 1ull << mr->log_n, L = N / W;
     ACX_TRY(mg_ensure_slots(mg, L));
@@ -768,15 +825,17 @@ int acx_mgpu_sync(acx_mgpu* mg) {
     return mg_sync(mg);
 }
 
-int acx_mgpu_r1cs_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C, acx_mgpu_r1cs** out) {
+int acx_mgpu_r1cs_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C, uint32_t flags,
+                       acx_mgpu_r1cs** out) {
     if (!mg || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     const acx_csr* mats[3] = {A, B, C};
     std::lock_guard<std::mutex> g(mg->mu);
     DevGuard dg;
-    return guarded([&]() -> int { return mg_load(mg, n, m, mats, out); });
+    return guarded([&]() -> int { return mg_load(mg, n, m, mats, flags, out); });
 }
 
-int acx_mgpu_circuit_to_r1cs(acx_mgpu* mg, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_mgpu_r1cs** out) {
+int acx_mgpu_circuit_to_r1cs(acx_mgpu* mg, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, uint32_t flags,
+                             acx_mgpu_r1cs** out) {
     if (!mg || !c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (c->field != mg->field) return fail(ACX_ERR_INVALID_ARG, "circuit and context are over different fields");
     std::lock_guard<std::mutex> g(mg->mu);
@@ -785,7 +844,7 @@ int acx_mgpu_circuit_to_r1cs(acx_mgpu* mg, const acx_circuit* c, const acx_fr* r
         const HostCircuit& hc = c->hc;
         const uint64_t n = hc.n_rows();
         const uint32_t log_n = ceil_log2(std::max<uint64_t>(n, 1));
-        const bool shard = log_n >= mg->min_log_n && (mg_can_distribute(mg->W, log_n) || (mg->W > 1 && log_n > 24));
+        const bool shard = log_n >= mg->min_log_n && (mg->W > 1 || mg_can_distribute(mg->W, log_n));
         if (!shard) {                                                   // small system: shard 0 holds it whole, with its evaluation plan
             std::unique_ptr<acx_mgpu_r1cs> mr(new acx_mgpu_r1cs());
             mr->mg = mg; mr->n = n; mr->m = hc.m(); mr->log_n = log_n;
@@ -804,7 +863,7 @@ int acx_mgpu_circuit_to_r1cs(acx_mgpu* mg, const acx_circuit* c, const acx_fr* r
             views[k] = acx_csr{src->rowptr.data(), src->col.data(), reinterpret_cast<const acx_fr*>(src->val.data())};
             mats[k] = &views[k];
         }
-        return mg_load(mg, n, hc.m(), mats, out);
+        return mg_load(mg, n, hc.m(), mats, flags, out);
     });
 }
 
@@ -868,6 +927,73 @@ int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* mr, const acx_fr* witness, int* ok, uint
     *ok = bad == 0;
     if (n_bad) *n_bad = bad;
     if (first_bad) *first_bad = first;
+    return ACX_OK;
+}
+
+// Throughput form of the resident check: enqueue accumulates the violated-row count of ONE verification into ring slot
+// `slot` on every device and returns at once; verdicts reduces a range of slots with ONE collective and waits.
+int acx_mgpu_r1cs_verify_enqueue(acx_mgpu_r1cs* mr, uint32_t slot) {
+    if (!mr || slot >= kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot < 16)");
+    if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
+    acx_mgpu* mg = mr->mg;
+    std::lock_guard<std::mutex> g(mg->mu);
+    DevGuard dg;
+    for (uint32_t s = 0; s < mg->W; ++s) {
+        MgShard& S = mg->sh[s];
+        HIP_TRY(hipSetDevice(S.device));
+        CtxLock lock(S.ctx->mu);
+        const auto& P = mr->part[s];
+        ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, P.ring + 2 * slot, nullptr, nullptr, 0));
+    }
+    return ACX_OK;
+}
+
+int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* mr, uint32_t slot0, uint32_t count, uint64_t* n_bad) {
+    if (!mr || !n_bad || count == 0 || slot0 + count > kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot0 + count <= 16)");
+    if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "system is held whole on shard 0");
+    acx_mgpu* mg = mr->mg;
+    std::lock_guard<std::mutex> g(mg->mu);
+    DevGuard dg;
+    const uint32_t W = mg->W;
+    std::vector<unsigned long long> host(2 * count), init(2 * count);
+    for (uint32_t i = 0; i < count; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
+    for (uint32_t i = 0; i < count; ++i) n_bad[i] = 0;
+    if (mg->rccl) {
+        // ONE all-reduce for the whole range ({n_bad, first_bad} pairs; the first_bad words are not meaningful after a
+        // sum): into the second half of the ring buffer
+        NCCL_TRY(mg, mg->api->GroupStart());
+        for (uint32_t s = 0; s < W; ++s) {
+            unsigned long long* ring = mr->part[s].ring;
+            const ncclResult_t r = mg->api->AllReduce(ring + 2 * slot0, ring + 2 * kMgRing + 2 * slot0, 2 * count, ncclUint64, ncclSum,
+                                                      mg->sh[s].comm, mg->sh[s].ctx->stream);
+            if (r != ncclSuccess) { (void)mg->api->GroupEnd(); return fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r)); }
+        }
+        NCCL_TRY(mg, mg->api->GroupEnd());
+        for (uint32_t s = 0; s < W; ++s) {
+            MgShard& S = mg->sh[s];
+            HIP_TRY(hipSetDevice(S.device));
+            if (s == 0) HIP_TRY(hipMemcpyAsync(host.data(), mr->part[0].ring + 2 * kMgRing + 2 * slot0, 16 * count, hipMemcpyDeviceToHost, S.ctx->stream));
+            HIP_TRY(hipMemcpyAsync(mr->part[s].ring + 2 * slot0, init.data(), 16 * count, hipMemcpyHostToDevice, S.ctx->stream));
+        }
+        for (uint32_t s = 0; s < W; ++s) {
+            HIP_TRY(hipSetDevice(mg->sh[s].device));
+            HIP_TRY(hipStreamSynchronize(mg->sh[s].ctx->stream));
+        }
+        for (uint32_t i = 0; i < count; ++i) n_bad[i] = host[2 * i];
+        return ACX_OK;
+    }
+    std::vector<std::vector<unsigned long long>> per(W, std::vector<unsigned long long>(2 * count));
+    for (uint32_t s = 0; s < W; ++s) {
+        MgShard& S = mg->sh[s];
+        HIP_TRY(hipSetDevice(S.device));
+        HIP_TRY(hipMemcpyAsync(per[s].data(), mr->part[s].ring + 2 * slot0, 16 * count, hipMemcpyDeviceToHost, S.ctx->stream));
+        HIP_TRY(hipMemcpyAsync(mr->part[s].ring + 2 * slot0, init.data(), 16 * count, hipMemcpyHostToDevice, S.ctx->stream));
+    }
+    for (uint32_t s = 0; s < W; ++s) {
+        HIP_TRY(hipSetDevice(mg->sh[s].device));
+        HIP_TRY(hipStreamSynchronize(mg->sh[s].ctx->stream));
+        for (uint32_t i = 0; i < count; ++i) n_bad[i] += per[s][2 * i];
+    }
     return ACX_OK;
 }
 

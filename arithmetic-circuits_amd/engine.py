@@ -442,7 +442,7 @@ class MultiGpu:
         check(self.lib.acx_mgpu_ntt(self._h, log_n, int(inverse), _ptr(sh), _ptr(arr), _ptr(out)))
         return out
 
-    def load(self, n: int, m: int, A, B, Cm) -> "MgR1CS":
+    def load(self, n: int, m: int, A, B, Cm, verify_only: bool = False) -> "MgR1CS":
         keep, structs = [], []
         for rowptr, col, val in (A, B, Cm):
             rp = np.ascontiguousarray(rowptr, dtype=np.uint32)
@@ -453,15 +453,17 @@ class MultiGpu:
             keep.append((rp, cl, vl))
             structs.append(_lib.Csr(_ptr(rp), _ptr(cl), _ptr(vl)))
         h = C.c_void_p()
-        check(self.lib.acx_mgpu_r1cs_load(self._h, n, m, C.byref(structs[0]), C.byref(structs[1]), C.byref(structs[2]), C.byref(h)))
+        check(self.lib.acx_mgpu_r1cs_load(self._h, n, m, C.byref(structs[0]), C.byref(structs[1]), C.byref(structs[2]),
+                                          1 if verify_only else 0, C.byref(h)))
         return MgR1CS(self, h)
 
-    def from_circuit(self, circuit: "Circuit", roots: Optional[np.ndarray] = None) -> "MgR1CS":
+    def from_circuit(self, circuit: "Circuit", roots: Optional[np.ndarray] = None, verify_only: bool = False) -> "MgR1CS":
         if circuit.field != self.field:
             raise ValueError("context and circuit are over different fields")
         h = C.c_void_p()
         r = _fr_array(roots) if roots is not None else None
-        check(self.lib.acx_mgpu_circuit_to_r1cs(self._h, circuit._h, _ptr(r), 0 if r is None else r.shape[0], C.byref(h)))
+        check(self.lib.acx_mgpu_circuit_to_r1cs(self._h, circuit._h, _ptr(r), 0 if r is None else r.shape[0],
+                                                1 if verify_only else 0, C.byref(h)))
         return MgR1CS(self, h)
 
 
@@ -510,6 +512,16 @@ class MgR1CS:
         ok, nbad, first = C.c_int(), C.c_uint64(), C.c_uint64(2**64 - 1)
         check(self.mg.lib.acx_mgpu_r1cs_verify_resident(self._h, C.byref(ok), C.byref(nbad), C.byref(first) if want_first else None))
         return bool(ok.value), nbad.value, first.value
+
+    def verify_enqueue(self, slot: int) -> None:
+        """asynchronous: one check of the resident witness accumulated into result slot `slot` (< 16) on every device"""
+        check(self.mg.lib.acx_mgpu_r1cs_verify_enqueue(self._h, slot))
+
+    def verdicts(self, slot0: int, count: int) -> np.ndarray:
+        """ONE collective: violated-row counts of slots [slot0, slot0 + count); waits and clears them"""
+        out = np.zeros(count, dtype=np.uint64)
+        check(self.mg.lib.acx_mgpu_r1cs_verdicts(self._h, slot0, count, _ptr(out)))
+        return out
 
     def qap_h_resident(self, delta: Optional[Sequence[int]] = None) -> bool:
         dl = ints_to_fr(list(delta)) if delta is not None else None

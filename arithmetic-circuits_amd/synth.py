@@ -188,6 +188,20 @@ class BlockSystem:
         """global index of wire k (>= 1) of one block"""
         return 1 + block * (self.m0 - 1) + (k - 1)
 
+    def full_rows(self) -> Tuple[Tuple[np.ndarray, np.ndarray, np.ndarray], ...]:
+        """CSR triples (A, B, C) of the whole system (the base system's arrays tiled `blocks` times, wires renumbered per
+        block): what a single-process host hands to acx_mgpu_r1cs_load."""
+        out = []
+        for rowptr, col, val in self.mats:
+            rp = np.asarray(rowptr, dtype=np.int64)
+            nnz0 = int(rp[-1])
+            full_rp = np.concatenate([[0]] + [rp[1:] + b * nnz0 for b in range(self.blocks)])
+            c = col.astype(np.int64)
+            shift = (np.arange(self.blocks, dtype=np.int64) * (self.m0 - 1)).reshape(-1, 1)
+            full_c = np.where(c.reshape(1, -1) == 0, 0, c.reshape(1, -1) + shift).reshape(-1)
+            out.append((full_rp.astype(np.uint32), full_c.astype(np.uint32), np.tile(val, (self.blocks, 1))))
+        return tuple(out)
+
     def rows_of(self, rows: np.ndarray) -> Tuple[Tuple[np.ndarray, np.ndarray, np.ndarray], ...]:
         """CSR triples (A, B, C) of the given global rows, in the given order; indices >= n are empty rows
         (the zero padding of the evaluation domain)."""

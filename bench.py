@@ -300,6 +300,101 @@ def bench_distributed(ctx, a, world, rank, dist):
     return out
 
 
+def main_mgpu(a, devices):
+    """The single-process launcher: ONE process drives all GPUs through acx_mgpu_* (include/acx.h) -- the shape of the
+    reference's callers -- instead of one rank per GPU under torch.distributed.run.  Same workload per GPU and step as the
+    multi-process path (`--copies` 2^logn-constraint mulgraph blocks per GPU: one block-diagonal system of
+    copies * W * 2^logn constraints, rows sharded by the library), same accounting: a STEP is one verification of the
+    device-resident witness over all GPUs (acx_mgpu_r1cs_verify_enqueue), the verdicts of 8 steps are combined by ONE
+    RCCL all-reduce (acx_mgpu_r1cs_verdicts).  `devices` may repeat an ordinal (several shards on one GPU: peer-copy
+    transport) to exercise the W > 1 path on a one-GPU box; the line says so."""
+    from oracle.c_oracle import COracle
+    W = len(devices)
+    mg = acx.MultiGpu(a.field, devices)
+    n0 = 1 << a.logn
+    base = synth.mulgraph(n0, seed=0xAC355, field=a.field)
+    bs = synth.BlockSystem(base, a.copies * W)
+    mats = bs.full_rows()
+    w = bs.witness()
+    t_load = time.perf_counter()
+    mr = mg.load(bs.n, bs.m, *mats)
+    t_load = time.perf_counter() - t_load
+    assert mr.n_shards == W
+    b0, nnz0, _ = algorithmic_bytes(bs.mats, n0)
+    bytes_per_launch = b0 * a.copies                     # per GPU
+    mr.upload_witness(w)
+    stream0 = torch.cuda.ExternalStream(mg.stream(0), device=torch.device("cuda", devices[0]))
+    ring = 8
+
+    def step(i):
+        k = i % (2 * ring)
+        mr.verify_enqueue(k)
+        if k % ring == ring - 1:
+            bad = mr.verdicts((k // ring) * ring, ring)
+            assert not bad.any(), "a satisfying witness was rejected"
+
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < a.prewarm:
+        for i in range(2 * ring):
+            step(i)
+    for i in range(a.warmup):
+        step(i)
+    assert not mr.verdicts(0, 2 * ring).any()
+    mg.sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream0)
+    for i in range(a.steps):
+        step(i)
+    e1.record(stream0)
+    assert not mr.verdicts(0, 2 * ring).any(), "a satisfying witness was rejected"     # ONE collective + wait: the clock stops after it
+    mg.sync()
+    dt = time.perf_counter() - t0
+    kernel_us = e0.elapsed_time(e1) * 1e3 / a.steps
+    # parity gates outside the timed region: the corrupted witness must be caught with the oracle's count and first row
+    orc = COracle(a.field)
+    wb = w.copy()
+    wb[bs.wire(a.copies * W - 1, 77), 0] ^= np.uint64(1)
+    _, nbad0, first0 = orc.r1cs_residuals(n0, bs.m0, *bs.mats, np.concatenate([wb[:1], wb[-(bs.m0 - 1):]]), nthreads=os.cpu_count() or 1)
+    got = mr.verify(wb)
+    parity = bool(nbad0 > 0 and got == (False, nbad0, (a.copies * W - 1) * n0 + first0))
+    out = {
+        "metric": "R1CS constraints/sec (verifyAssignment over %s Fr, bit-exact vs oracle)" % ("BN254" if a.field == "bn254" else "BLS12-381"),
+        "value": bs.n * a.steps / dt, "unit": "constraints/s", "n_gpus": len(set(devices)), "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u256 (9x29-bit limbs, Montgomery)", "data": "synthetic",
+        "launcher": f"single process, acx_mgpu_* over {W} shard(s) on devices {devices} ({mg.transport})",
+        "config": {"workload": f"r1cs_verify: ONE block-diagonal system of {a.copies} x {W} mulgraph blocks of 2^{a.logn} constraints "
+                               f"(k=2, n_in=1024, window=4096, seed 0xAC355), rows sharded by libacx in nnz-balanced slabs; a step = one "
+                               f"verification of the resident witness on every GPU, 1 verdict all-reduce per {ring} steps",
+                   "constraints_per_step_per_gpu": a.copies * n0, "field": a.field + "_fr", "load_s": t_load,
+                   "parallelism": f"{W} shards x {a.copies} blocks (weak scaling)"},
+        "parity_vs_oracle": parity,
+        "roofline": _hbm(bytes_per_launch, kernel_us, kernel="acx::k_r1cs_sell_split (shard 0's stream)", kernel_us=kernel_us,
+                         traffic=None, traffic_measured_in_run=False),
+    }
+    ln = (bs.n - 1).bit_length()
+    if not a.no_dist_pipeline and mr.n == 1 << ln and ln <= 24:
+        ok = mr.qap_h_resident()                       # first call: buffers, tables
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ok = mr.qap_h_resident() and ok
+        mg.sync()
+        sec = (time.perf_counter() - t1) / reps
+        mr.upload_witness(wb)
+        ok_bad = mr.qap_h_resident()
+        out["mgpu_qap_h"] = {"workload": f"acx_mgpu_qap_h_resident: verificationWitness h(x) of the same 2^{ln}-constraint system over {W} shard(s): "
+                                         f"block-cyclic rows, 6 all-to-alls + 1 all-reduce per call, blocking call",
+                             "accepts_valid_rejects_corrupt": bool(ok and not ok_bad), "us": sec * 1e6, "constraints_per_s": bs.n / sec}
+    mr.close()
+    mg.close()
+    sys.stdout.flush()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,7 +414,16 @@ def main():
     ap.add_argument("--no-dist-pipeline", action="store_true", help="skip the distributed NTT / h(x) measurements of a multi-rank run")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "ranks", "mgpu"],
+                    help="ranks: one process per GPU (torch.distributed.run, what the driver uses); mgpu: ONE process, all GPUs "
+                         "through acx_mgpu_*; auto: mgpu when --gpus N > 1 is asked for outside torch.distributed.run")
+    ap.add_argument("--mgpu-devices", default=None,
+                    help="device ordinals of the mgpu launcher, e.g. 0,1,2,3 or 0,0 (repeats = several shards on one GPU); default 0..N-1")
     a = ap.parse_args()
+    in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if a.launcher == "mgpu" or (a.launcher == "auto" and not in_torchrun and (a.gpus > 1 or a.mgpu_devices)):
+        devices = [int(x) for x in a.mgpu_devices.split(",")] if a.mgpu_devices else list(range(a.gpus))
+        return main_mgpu(a, devices)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -490,6 +594,7 @@ def main():
             "value": value, "unit": "constraints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u256 (9x29-bit limbs, Montgomery)", "data": "synthetic",
+            "launcher": "one process per GPU (torch.distributed.run), collectives through torch.distributed/RCCL" if use_dist else "single process, one GPU",
             "config": {"workload": f"r1cs_verify: {a.copies} independent 2^{a.logn}-constraint mulgraph systems per GPU per "
                                    f"step, one batched launch (k=2, n_in=1024, window=4096, seeds 0xAC355+1000*rank+c)",
                        "constraints_per_step_per_gpu": a.copies * n, "nnz_per_step_per_gpu": nnz_total,

@@ -343,6 +343,7 @@ void acx_batch_destroy(acx_batch* batch);
 typedef struct acx_mgpu acx_mgpu;
 typedef struct acx_mgpu_r1cs acx_mgpu_r1cs;
 enum { ACX_MGPU_RCCL = 0, ACX_MGPU_PEER_COPY = 1 };
+enum { ACX_MGPU_VERIFY_ONLY = 1 };      /* load flag: no block-cyclic copy (acx_mgpu_qap_h then reports ACX_ERR_UNSUPPORTED) */
 
 /* replaces acx_ctx_create for a multi-GPU host (SURVEY.md 8b proposed `device_ids[], n_devices`) */
 int acx_mgpu_create(int field, const int* device_ids, uint32_t n_devices, acx_mgpu** out);
@@ -355,10 +356,15 @@ int acx_mgpu_set_root(acx_mgpu* mg, uint32_t two_adicity, const acx_fr* omega); 
 int acx_mgpu_sync(acx_mgpu* mg);
 
 /* acx_r1cs_load / acx_circuit_to_r1cs (`arithCircuitToGenQAP`, src/QAP.hs:530-539) with the rows sharded over the devices:
- * each shard's rows are gathered and uploaded by its own host thread; no device ever holds the whole system. */
+ * each shard's rows are gathered and uploaded by its own host thread; no device ever holds the whole system.  Two row
+ * ownerships are kept (memory is plentiful: 288 GB per GPU, a 2^24-constraint system is ~1 GB per GPU per copy): contiguous
+ * slabs balanced by entry count for verifyAssignment (the rows in flight on a GPU then gather from one narrow window of the
+ * witness: 1.5-2x on the residual kernel), and the block-cyclic rows whose dot products ARE the transforms' input layout for
+ * h(x).  flags: 0, or ACX_MGPU_VERIFY_ONLY to skip the second copy. */
 int acx_mgpu_r1cs_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C,
-                       acx_mgpu_r1cs** out);
-int acx_mgpu_circuit_to_r1cs(acx_mgpu* mg, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_mgpu_r1cs** out);
+                       uint32_t flags, acx_mgpu_r1cs** out);
+int acx_mgpu_circuit_to_r1cs(acx_mgpu* mg, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, uint32_t flags,
+                             acx_mgpu_r1cs** out);
 void acx_mgpu_r1cs_destroy(acx_mgpu_r1cs* r);
 int acx_mgpu_r1cs_dims(const acx_mgpu_r1cs* r, uint64_t* n, uint64_t* m, uint32_t* log_n, uint32_t* n_shards);
 
@@ -377,6 +383,11 @@ int acx_mgpu_witness_upload(acx_mgpu_r1cs* r, const acx_fr* witness);
 int acx_mgpu_r1cs_verify_resident(acx_mgpu_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* first_bad);
 int acx_mgpu_qap_h_resident(acx_mgpu_r1cs* r, const acx_fr* delta, int* ok);
 int acx_mgpu_qap_h_fetch(acx_mgpu_r1cs* r, acx_fr* out_h, uint64_t* h_len);
+/* Throughput form (`all (verifyAssignment qap) inputs` with the inputs resident): enqueue adds the violated-row count of one
+ * check of the resident witness to result slot `slot` (< 16) on every device and returns without waiting; verdicts combines
+ * the slots [slot0, slot0 + count) with ONE all-reduce, waits, returns the counts and clears the slots. */
+int acx_mgpu_r1cs_verify_enqueue(acx_mgpu_r1cs* r, uint32_t slot);
+int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* r, uint32_t slot0, uint32_t count, uint64_t* n_bad);
 
 #ifdef __cplusplus
 }

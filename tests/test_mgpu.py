@@ -73,8 +73,25 @@ def test_mgpu_verify_and_h_equal_single_gpu_and_oracle(acx, request, field, devi
     assert mr.verify_resident() == (True, 0, U64_MAX)
     assert mr.qap_h_resident()
     assert np.array_equal(mr.qap_h_fetch(), h)
+    # throughput form: checks enqueued into result slots, ONE collective for a range of slots
+    for k in range(4):
+        mr.verify_enqueue(k)
+    assert mr.verdicts(0, 4).tolist() == [0, 0, 0, 0]
+    mr.upload_witness(bad)
+    mr.verify_enqueue(2)
+    mr.verify_enqueue(2)
+    mr.verify_enqueue(5)
+    assert mr.verdicts(2, 4).tolist() == [2 * nbad, 0, 0, nbad]
+    assert mr.verdicts(0, 16).tolist() == [0] * 16              # read slots are cleared
     r1.close()
     mr.close()
+    # verification-only load: no block-cyclic copy, h(x) is refused, the verdict is the same
+    mv = mg.from_circuit(s.circuit, verify_only=True)
+    assert mv.verify(bad) == (False, nbad, first) and mv.verify(w) == (True, 0, U64_MAX)
+    with pytest.raises(acx.AcxError) as e:
+        mv.qap_h(w)
+    assert e.value.status == acx._lib.STATUS["UNSUPPORTED"]
+    mv.close()
 
 
 @pytest.mark.parametrize("devices", DEVICE_LISTS, ids=lambda d: f"W{len(d)}")
