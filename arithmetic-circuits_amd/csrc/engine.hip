@@ -405,7 +405,7 @@ int get_limb_table(acx_ctx* c, uint32_t log_m, int inverse, uint4** out) {
     if (it != c->tw_limbs.end()) { *out = it->second; return ACX_OK; }
     const uint64_t count = std::max<uint64_t>(1, (1ull << log_m) / 2);
     uint4* tw = nullptr;
-    HIP_TRY(hipMalloc((void**)&tw, count * 48));
+    HIP_TRY(hipMalloc((void**)&tw, count * 16 * kLimbEntryQuads));
     H256 w = c->hf.root_of_unity((int)log_m);
     if (inverse) w = c->hf.inv(w);
     DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pow_table_limbs<F>), dim3(grid_for(c, count)), dim3(kBlock), 0, cur_stream(c), tw,
@@ -865,13 +865,16 @@ inline int sell_spec_join(int a, int b) { return a == b ? a : 2; }
 // grid.x is sized by sell_grid_x for the launch's largest system: one workgroup (two waves) per slice.
 inline void launch_sell(acx_ctx* c, int spec, dim3 grid, const SellSystem* systems, const SellSystem& one) {
     DISPATCH_FIELD(c, {
-        if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell_split<F, 0>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
-        else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell_split<F, 1>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
-        else hipLaunchKernelGGL((k_r1cs_sell_split<F, 2>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
+        if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell_split<F, 0>), grid, dim3(2 * kSlice * kK2Slices), 0, cur_stream(c), systems, one);
+        else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell_split<F, 1>), grid, dim3(2 * kSlice * kK2Slices), 0, cur_stream(c), systems, one);
+        else hipLaunchKernelGGL((k_r1cs_sell_split<F, 2>), grid, dim3(2 * kSlice * kK2Slices), 0, cur_stream(c), systems, one);
     });
 }
 
-inline unsigned sell_grid_x(uint32_t n_slices) { return ((n_slices + 7) / 8) * 8; }   // multiple of 8: the XCD remap is a bijection
+inline unsigned sell_grid_x(uint32_t n_slices) {          // workgroups, a multiple of 8: the XCD remap is a bijection
+    const uint32_t tiles = (n_slices + kK2Slices - 1) / kK2Slices;
+    return ((tiles + 7) / 8) * 8;
+}
 
 // rows too long for SELL go through the CSR kernel
 int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out, const SellSystem* d_many = nullptr, uint32_t n_many = 1) {
