@@ -22,7 +22,10 @@
 #include "circuit_host.h"
 #include "host_field.h"
 #include "kernels.hip.h"
-#include "ntt_r4.hip.h"
+
+namespace acx {
+bool launch_ntt_r4(bool bls12_381, int lp, int lg, unsigned tiles, hipStream_t st, const NttPass& Q);      // ntt_r4.hip
+}
 
 using namespace acx;
 
@@ -520,21 +523,7 @@ NttCfg ntt_cfg_from_env() {
     return g;
 }
 
-// (LP, LG) instances of k_ntt_r4 that are compiled
-template <class F>
-bool launch_r4(int lp, int lg, unsigned tiles, hipStream_t st, const NttPass& Q) {
-#define ACX_R4_CASE(LP_, LG_)                                                                                    \
-    if (lp == LP_ && lg == LG_) {                                                                               \
-        hipLaunchKernelGGL((k_ntt_r4<F, LP_, LG_>), dim3(tiles), dim3(1u << (LP_ - 2 + LG_)), 0, st, Q);   \
-        return true;                                                                                            \
-    }
-    ACX_R4_CASE(6, 0) ACX_R4_CASE(6, 2) ACX_R4_CASE(6, 4)
-    ACX_R4_CASE(8, 0) ACX_R4_CASE(8, 2)
-    ACX_R4_CASE(10, 0) ACX_R4_CASE(10, 1) ACX_R4_CASE(10, 2)
-    ACX_R4_CASE(12, 0)
-#undef ACX_R4_CASE
-    return false;
-}
+// (LP, LG) instances of k_ntt_r4 that are compiled (ntt_r4.hip)
 inline int r4_pick_lg(int lp, int want) {      // largest compiled LG <= want, or -1
     static const int kLg[4][3] = {{0, 2, 4}, {0, 2, -1}, {0, 1, 2}, {0, -1, -1}};
     const int* row = kLg[(lp - 6) / 2];
@@ -727,10 +716,7 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         const uint64_t tiles = batch * N / (S * T);
         if (tiles > 0x7fffffffull) return fail(ACX_ERR_TOO_LARGE, "NTT grid too large");
         if (r4) {
-            bool ok = false;
-            DISPATCH_FIELD(c, {
-                ok = launch_r4<F>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
-            });
+            const bool ok = launch_ntt_r4(c->field == ACX_FIELD_BLS12_381_FR, lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
             if (!ok) return fail(ACX_ERR_UNSUPPORTED, "NTT plan: kernel instance missing");
         } else {
             DISPATCH_FIELD(c, hipLaunchKernelGGL((k_ntt_tile<F>), dim3((unsigned)tiles), dim3(kBlock), 0, cur_stream(c), Q));
@@ -831,10 +817,7 @@ int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t wo
         if (inverse) Q.scale_mode = 2; else Q.scale_on_load = 1;
     }
     const uint64_t tiles = cols / T;
-    bool ok = false;
-    DISPATCH_FIELD(c, {
-        ok = launch_r4<F>(lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
-    });
+    const bool ok = launch_ntt_r4(c->field == ACX_FIELD_BLS12_381_FR, lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
     if (!ok) return fail(ACX_ERR_UNSUPPORTED, "distributed NTT step: kernel instance missing");
     HIP_TRY(hipGetLastError());
     return ACX_OK;

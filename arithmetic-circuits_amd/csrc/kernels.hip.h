@@ -2,6 +2,8 @@
 // (pure Haskell) has no kernels; each kernel names the reference computation it performs.
 #pragma once
 #include "fr.hip.h"
+#include "mem.hip.h"
+#include "ntt_pass.hip.h"
 
 namespace acx {
 
@@ -14,6 +16,9 @@ constexpr int kBlock = 256;
 #endif
 #ifndef ACX_K2_PIPE
 #define ACX_K2_PIPE 0          // development A/B switch of the residual kernel's software pipeline (profiles/r03_r1cs.txt)
+#endif
+#ifndef ACX_K2_NOPEEL
+#define ACX_K2_NOPEEL 0
 #endif
 #ifndef ACX_K2_HOT
 #define ACX_K2_HOT 0           // A/B: the first ACX_K2_HOT wires (constant + inputs) served from an LDS copy, four slices per workgroup
@@ -178,45 +183,6 @@ __global__ __launch_bounds__(kBlock) void k_build_sell_small(CsrDev M, const u32
     }
 }
 
-// Pointers that reach a kernel through a descriptor in memory (SellSystem) have no known address
-// space and hipcc emits flat_load for them (counted against lgkmcnt as well as vmcnt, and split into
-// odd 4/16/12-byte pieces for the 32-byte gathers).  These helpers pin the global address space
-// and the access width: one global_load_dwordx4 / dwordx2 per call.
-typedef __attribute__((address_space(1))) const uint4 g_uint4;
-typedef __attribute__((address_space(1))) const uint2 g_uint2;
-typedef __attribute__((address_space(1))) const u32 g_u32;
-typedef u32 v2u32 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) const v4u32 g_v4u32;
-typedef __attribute__((address_space(1))) const v2u32 g_v2u32;
-
-__device__ __forceinline__ uint4 gload(const uint4* p) {
-    const v4u32 r = *(g_v4u32*)p;
-    return make_uint4(r.x, r.y, r.z, r.w);
-}
-__device__ __forceinline__ uint2 gload(const uint2* p) {
-    const v2u32 r = *(g_v2u32*)p;
-    return make_uint2(r.x, r.y);
-}
-__device__ __forceinline__ u32 gload(const u32* p) { return *(g_u32*)p; }
-// a wave-uniform word through the scalar cache (constant address space: s_load_dword)
-typedef __attribute__((address_space(4))) const u32 c_u32;
-__device__ __forceinline__ u32 sload(const u32* p) { return *(c_u32*)(unsigned long long)p; }
-// The constraint stream is read exactly once per verification: non-temporal loads keep it from
-// evicting the witness window (re-read by every row) out of the XCD's L2.
-__device__ __forceinline__ uint4 nt_load(const uint4* p) {
-    const v4u32 r = __builtin_nontemporal_load((g_v4u32*)p);
-    return make_uint4(r.x, r.y, r.z, r.w);
-}
-__device__ __forceinline__ uint2 nt_load(const uint2* p) {
-    const v2u32 r = __builtin_nontemporal_load((g_v2u32*)p);
-    return make_uint2(r.x, r.y);
-}
-__device__ __forceinline__ Fe fe_gload(const uint4* p) {
-    const uint4 lo = gload(p), hi = gload(p + 1);
-    const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    return fe_unpack(w);
-}
-
 // where a witness element comes from: global memory, or (ACX_K2_HOT) the workgroup's LDS copy of the first wires
 typedef __attribute__((address_space(3))) const v4u32 lds_v4u32;
 struct WitSrc {
@@ -279,6 +245,7 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 sl
     // Gather one slot AHEAD as well: in iteration q the gather of slot q+1 (its column arrived with the tail word loaded
     // two slots ahead), the values of slot q+1 and the tail of slot q+2 are issued before the products of slot q, whose
     // operands were requested a whole iteration earlier.
+    wide_zero(wide);
     uint2 t0 = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
     uint2 t1 = t0;
     if (q0 + 1 < q1) t1 = nt_load(&M.tail[(u64)(q0 + 1) * kSlice + lane]);
@@ -286,12 +253,14 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 sl
     uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
     const uint4* px = w + 2 * (u64)(t0.y == kNoRow ? 0u : t0.y);
     uint4 xlo = gload(px), xhi = gload(px + 1);
+#pragma unroll 1
     for (u32 q = q0; q < q1; ++q) {
         Fe v;
         v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
         v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
         v.l[8] = t0.x;
         const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
+        const Fe x = fe_unpack(xw);
         if (q + 1 < q1) {
             const uint4* pn = w + 2 * (u64)(t1.y == kNoRow ? 0u : t1.y);
             xlo = gload(pn);
@@ -301,8 +270,7 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 sl
             t0 = t1;
             if (q + 2 < q1) t1 = nt_load(&M.tail[(u64)(q + 2) * kSlice + lane]);
         }
-        const Fe x = fe_unpack(xw);
-        if (q == q0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
+        wide_mac(wide, v, x);
     }
     return wide_reduce<F>(wide);
 #elif ACX_K2_LAYOUT == 1
@@ -329,6 +297,10 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 sl
     uint2 t = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
     uint4 lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
     uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
+#if ACX_K2_NOPEEL
+    wide_zero(wide);
+#pragma unroll 1
+#endif
     for (u32 q = q0; q < q1; ++q) {
         uint4 xlo, xhi;
         wit_load(G, t.y == kNoRow ? 0u : t.y, xlo, xhi);             // padding: value 0 * w[0]
@@ -343,7 +315,11 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 sl
         }
         const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
         const Fe x = fe_unpack(xw);
+#if ACX_K2_NOPEEL
+        wide_mac(wide, v, x);
+#else
         if (q == q0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
+#endif
     }
     return wide_reduce<F>(wide);
 #endif
@@ -631,7 +607,6 @@ __global__ __launch_bounds__(kBlock) void k_pow_table_scaled(uint4* __restrict__
 // limb-form table for k_ntt_r4: entry j = 5 x uint4 = the nine 29-bit limbs of w = base^j (CANONICAL: fe_mul_pre's bound
 // needs w < p) followed by the nine limbs of w'' = w * NP mod R (fe_mul_pre's precomputed quotient factor); no unpacking
 // in the kernel
-constexpr int kLimbEntryQuads = 5;
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_pow_table_limbs(uint4* __restrict__ tw, u64 count, FeArg base_arg) {
     const Fe base = fe_from_arg(base_arg);
@@ -655,70 +630,7 @@ __global__ __launch_bounds__(kBlock) void k_pow_table_limbs(uint4* __restrict__ 
     }
 }
 
-// ---- K3/K4: tiled multi-pass NTT ---------------------------------------------------------------
-// A length-N transform is factored N = N_1 * ... * N_P (P <= 4, every N_p <= 256).  Pass p runs
-// all the length-N_p sub-transforms over digit p of the index; a workgroup owns a tile of
-// S = N_p points x T columns (S*T = 1024 elements, 36 KiB of LDS in limb-plane form, so four
-// workgroups share a CU and one tile's global load/store overlaps the others' butterflies).
-// T consecutive elements of the fastest-varying remaining digit form a 32*T-byte segment: every
-// global access is a full 128/256-byte line.  Inside the tile: bit-reversed placement on load,
-// log2(S) radix-2 DIT stages out of LDS with lazy (carry-only) add/sub, then ONE multiplication
-// per element that both applies the inter-pass twiddle w_N^(I*K) (or the final 1/N, coset factor)
-// and brings the lazily grown value back below 2p.  The last pass stores in natural order, so
-// there is no separate transpose or bit-reversal kernel and no barrier between workgroups.
-constexpr int kTileElems = 1024;
-constexpr int kMaxOuter = 4;
-
-struct NttOuter {          // one outer loop dimension of the tile enumeration
-    u32 count;             // number of values
-    u32 pad;
-    u64 stride_in, stride_out;   // element strides
-    u64 k_w, i_w;          // contribution of this index to the twiddle factors K and I
-};
-
-struct NttPass {
-    const uint4* src;
-    uint4* dst;
-    const uint4* sub_tw;   // w_S^j, j < S/2 (dev format, strictly normalised)
-    const uint4* tw_lo;    // twiddle table: direct (w_M^e, e < M) or low level of a two-level table
-    const uint4* tw_hi;    // high level (w^(1024 j)) or null
-    const uint4* sc_lo;    // coset powers g^j (j < 1024) or null
-    const uint4* sc_hi;    // g^(1024 j) or null
-    u32 log_s, log_t;      // S points, T columns
-    u32 n_outer;
-    u32 tw_mode;           // 0 none, 1 direct table index (I*K) >> tw_shift, 2 two-level on (I*K) & tw_mask
-    u32 tw_shift;
-    u32 scale_mode;        // 0 none, 1 multiply by `scale`, 2 scale * g^(element index) via sc_lo/sc_hi, 3 (k_ntt_r4) g^(index) from the direct table sc_lo
-    u32 scale_on_load;     // coset pre-multiplication of a forward transform (first pass)
-    u32 pad;
-    u64 scale_off_end;     // scale_mode 3 (k_ntt_r4): outputs at offsets >= this take the plain reduction (0 = no bound): the
-                           // leading vectors of a batch get the coset factor, the rest do not (h(x): L and R, not O)
-    u64 tw_mask;
-    u64 stride_t_in, stride_t_out;   // transform direction
-    u64 stride_c_in, stride_c_out;   // column direction
-    u64 t_kw;              // K contribution of the output digit k_p
-    u64 c_kw, c_iw;        // K / I contribution of the column index
-    u64 idx_mask;          // element index within its transform = offset & idx_mask (coset exponent)
-    // --- used by k_ntt_r4 only (local steps of the distributed four-step transform, acx_ntt_dist_step_dev) ---
-    // transform-direction offset of digit d = (d & (2^split - 1)) * stride_t + (d >> split) * stride_t_hi;
-    // the planner's default split = 0, stride_t_hi = stride_t is the plain single stride.
-    u32 split_in, split_out;
-    u64 stride_t_in_hi, stride_t_out_hi;
-    u64 k_base, i_base;    // constants added to the twiddle factors K and I (this rank's block offset)
-    u32 e_mode;            // coset exponent: 0 = offset & idx_mask, 1 = e_base + digit * e_t + I * e_c (I = the column's global index)
-    u32 pad2;
-    u64 e_base, e_t, e_c;
-    NttOuter outer[kMaxOuter];
-    FeArg scale;
-};
-
-template <class F>
-__device__ __forceinline__ Fe two_level_pow(const uint4* __restrict__ lo, const uint4* __restrict__ hi, u64 e) {
-    const Fe a = fe_load(lo + 2 * (e & 1023));
-    if (hi == nullptr) return a;
-    return fe_mul<F>(a, fe_load(hi + 2 * (e >> 10)));
-}
-
+// ---- K3/K4: tiled multi-pass NTT (pass descriptor and planning constants: ntt_pass.hip.h) ----------
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_ntt_tile(NttPass P) {
     __shared__ u32 lds[kLimbs][kTileElems];

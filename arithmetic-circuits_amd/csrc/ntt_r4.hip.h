@@ -23,7 +23,7 @@
 //     contiguous input row is also read in lane order.
 //   * XOR-swizzled LDS addresses make both sides of every exchange bank-conflict free.
 #pragma once
-#include "kernels.hip.h"
+#include "ntt_pass.hip.h"
 
 #ifndef ACX_NTT_PRE
 #define ACX_NTT_PRE 1          // butterfly products by table twiddles through fe_mul_pre (0: plain fe_mul; A/B switch)
@@ -68,20 +68,15 @@ __device__ __forceinline__ Twiddle fe_load_limbs(const uint4* __restrict__ tab, 
     r.wpp.l[7] = f.x; r.wpp.l[8] = f.y;
     return r;
 }
+// BN254 Fr takes fe_mul_pre; BLS12-381 Fr keeps fe_mul: its modulus has P[0] = 1 and N0 = -1, so fe_mul is already 152
+// multiplier instructions there, and the second table operand pushes its instances over the 128 registers a 1024-thread
+// workgroup may use (84-100 bytes of scratch per lane under either scheduler; tools/kres.sh, profiles/r03_ntt.txt).
+template <class F> struct TwiddlePre { static constexpr bool value = ACX_NTT_PRE != 0; };
+template <> struct TwiddlePre<Bls12381Fr> { static constexpr bool value = false; };
 template <class F>
 __device__ __forceinline__ Fe tw_mul(const Fe& x, const Twiddle& t) {
-#if ACX_NTT_PRE
-#ifdef ACX_NTT_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-    const Fe r = fe_mul_pre<F>(x, t.w, t.wpp);
-    __builtin_amdgcn_sched_barrier(0);
-    return r;
-#else
-    return fe_mul_pre<F>(x, t.w, t.wpp);
-#endif
-#else
-    return fe_mul<F>(x, t.w);
-#endif
+    if constexpr (TwiddlePre<F>::value) return fe_mul_pre<F>(x, t.w, t.wpp);
+    else return fe_mul<F>(x, t.w);
 }
 
 // One round on the four slots: stage A pairs (0,1),(2,3) with twiddle wA, stage B pairs (0,2),(1,3) with

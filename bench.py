@@ -375,6 +375,7 @@ def main_mgpu(a, devices):
     }
     ln = (bs.n - 1).bit_length()
     if not a.no_dist_pipeline and mr.n == 1 << ln and ln <= 24:
+        mr.upload_witness(w)                           # the parity gate above left the corrupted witness resident
         ok = mr.qap_h_resident()                       # first call: buffers, tables
         t1 = time.perf_counter()
         reps = 3

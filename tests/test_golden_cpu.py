@@ -67,3 +67,52 @@ def test_field_cases_c_oracle(case):
             assert orc.op("inv", a) == pow(a, -1, p)
     for k, w in case["roots_of_unity"].items():
         assert orc.root_of_unity(int(k)) == int(w, 16)
+
+
+def test_ghc_vector_checker_accepts_the_fixtures_and_names_a_difference(tmp_path):
+    """tools/ghc_vectors/check.py is what turns a dump of the real Haskell library (tools/ghc_vectors/Main.hs, for a
+    machine with GHC) into a verdict on the derived fixtures.  Fed a dump synthesised from the fixtures themselves, in
+    the aeson shape the library would emit, it must accept; with one coefficient or one root of unity changed it must
+    name the convention."""
+    import json, os, subprocess, sys
+    from oracle import ref_qap as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "qap_cases.json")))[:3]
+
+    def qs(polys, dims):
+        out = {"qapSetConstant": [int(x, 16) for x in polys.get("0", [])], "qapSetInput": {}, "qapSetIntermediate": {}, "qapSetOutput": {}}
+        base = 1
+        for key, size in (("qapSetInput", dims[0]), ("qapSetIntermediate", dims[1]), ("qapSetOutput", dims[2])):
+            for k in range(size):
+                if str(base + k) in polys:
+                    out[key][str(k)] = [int(x, 16) for x in polys[str(base + k)]]
+            base += size
+        return out
+
+    cases = []
+    for g in gold:
+        c = {"name": g["name"],
+             "qap": {"qapTarget": [int(x, 16) for x in g["target"]], "qapInputsLeft": qs(g["polys"]["A"], g["dims"]),
+                     "qapInputsRight": qs(g["polys"]["B"], g["dims"]), "qapOutputs": qs(g["polys"]["C"], g["dims"])},
+             "assignments": [{"valid": a["valid"], "assignment": None,
+                              "h": None if a.get("h") is None else [int(x, 16) for x in a["h"]],
+                              "h_zk": None if a.get("h_zk") is None else [int(x, 16) for x in a["h_zk"]]} for a in g["assignments"]]}
+        if g["name"] == "example_hs":
+            c["circuit"] = json.load(open(os.path.join(root, "tests", "golden", "aeson_example_circuit.json")))
+            c["assignments"][0]["assignment"] = json.load(open(os.path.join(root, "tests", "golden", "aeson_example_assignment.json")))
+        cases.append(c)
+    dump = {"roots_of_unity": [R.BN254.root_of_unity(k) for k in range(29)], "cases": cases}
+    check = os.path.join(root, "tools", "ghc_vectors", "check.py")
+
+    def run(d):
+        path = tmp_path / "dump.json"
+        path.write_text(json.dumps(d))
+        return subprocess.run([sys.executable, check, str(path)], capture_output=True, text=True)
+
+    ok = run(dump)
+    assert ok.returncode == 0 and "all derived fixtures match" in ok.stdout, ok.stdout + ok.stderr
+    bad = json.loads(json.dumps(dump))
+    bad["roots_of_unity"][28] += 1
+    bad["cases"][0]["qap"]["qapInputsLeft"]["qapSetInput"]["0"][1] += 1
+    out = run(bad)
+    assert out.returncode == 1 and "getRootOfUnity table differs" in out.stdout and "FFT.interpolate point order" in out.stdout

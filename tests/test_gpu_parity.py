@@ -1410,3 +1410,70 @@ def test_equal_gate_inversion_edge_values(request, acx, field):
         m, out = wi[1 + n_in + i], wi[1 + 2 * n_in + i]
         assert (m, out) == ((pow(v, -1, p), 1) if v else (0, 0))
     assert r.verify_resident()[0]
+
+
+# ------------------------------------------------------------------ f-2: aeson-shaped JSON through the HIP path
+def test_json_loaded_example_runs_on_the_device(request, acx):
+    """SURVEY.md 8f-2 on the device: tests/golden/aeson_example_circuit.json + aeson_example_assignment.json (the
+    reference's Example.hs in the shape of its aeson instances) -> json_io -> acx_circuit_create -> acx_circuit_to_r1cs ->
+    acx_r1cs_verify / acx_qap_h: "Valid assignment", h = [42]; and the same through a two-shard acx_mgpu handle."""
+    import importlib, json
+    jio = importlib.import_module("arithmetic-circuits_amd.json_io")
+    ctx = _ctx(request, "bn254")
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    program = jio.circuit_from_json(json.load(open(os.path.join(gdir, "aeson_example_circuit.json"))))
+    assignment = jio.qapset_from_json(json.load(open(os.path.join(gdir, "aeson_example_assignment.json"))))
+    roots = acx.freshRoots(program, 1)
+    qap = acx.arithCircuitToQAPFFT(ctx, roots, program)
+    assert acx.verifyAssignment(qap, assignment)
+    assert acx.verificationWitness(qap, assignment) == [42]
+    assert assignment == acx.generateAssignment(program, {0: 7, 1: 5, 2: 4})
+    w = qap.gen.witness_vector(assignment)
+    r = qap.gen.r1cs
+    assert r.verify(w) == (True, 0, 2**64 - 1)
+    h, ok = r.qap_h(w)
+    assert ok and acx.fr_to_ints(h) == [42]
+    mg = acx.MultiGpu("bn254", [0, 0])
+    try:
+        mr = mg.from_circuit(program.marshal("bn254"), acx.ints_to_fr([x for rs in roots for x in rs]))
+        assert mr.verify(w) == (True, 0, 2**64 - 1)
+        hm, okm = mr.qap_h(w)
+        assert okm and acx.fr_to_ints(hm) == [42]
+        mr.close()
+    finally:
+        mg.close()
+
+
+def test_json_all_constructors_runs_on_the_device_against_the_oracle(request, acx):
+    """tests/golden/aeson_all_constructors.json (ScalarMul, Add, ConstGate, Var; Mul, Equal, Split; all three wire kinds)
+    loaded through json_io and driven through the HIP path: rows, verdicts, residuals and h(x) against the oracle's
+    literal restatement of the same gate list, for satisfying and corrupted assignments."""
+    import importlib, json
+    jio = importlib.import_module("arithmetic-circuits_amd.json_io")
+    ctx, orc = _ctx(request, "bn254"), _orc(request, "bn254")
+    p = ctx.p
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    program = jio.circuit_from_json(json.load(open(os.path.join(gdir, "aeson_all_constructors.json"))))
+    gates = [R.Mul(R.ScalarMul(p - 1, R.Var(R.InputWire(0))), R.Add(R.ConstGate(10), R.Var(R.InputWire(1))), R.IntermediateWire(0)),
+             R.Equal(R.IntermediateWire(0), R.IntermediateWire(1), R.IntermediateWire(2)),
+             R.Split(R.IntermediateWire(0), [R.IntermediateWire(3), R.IntermediateWire(4), R.OutputWire(0)])]
+    roots = acx.freshRoots(program, 1)
+    assert roots == R.fresh_roots(gates, 1)
+    gen = acx.arithCircuitToGenQAP(ctx, roots, program)
+    r = gen.r1cs
+    mats = [r.export(k) for k in range(3)]
+    for inputs in ({0: 5, 1: p - 11}, {0: 3, 1: 5}, {0: 0, 1: 7}):      # M0 = 5 (bits 101: valid), M0 = -45 (3 bits cannot hold it), M0 = 0
+        want = R.generate_assignment(gates, inputs, p)
+        a = acx.generateAssignment(program, inputs)
+        assert (a.qapSetConstant, a.qapSetInput, a.qapSetIntermediate, a.qapSetOutput) == (want.constant, want.inputs, want.intermediates, want.outputs)
+        w = gen.witness_vector(a)
+        oracle_qap = R.create_polynomials_fft(R.BN254.root_of_unity, R.arith_circuit_to_gen_qap(roots, gates, p), p)
+        # the 3-bit Split only holds for small values: the oracle's polynomial division decides, the device must agree
+        want_ok = R.verify_assignment(oracle_qap, want, p)
+        want_res, nbad, first = orc.r1cs_residuals(r.n, r.m, *mats, w)
+        assert (nbad == 0) == want_ok
+        assert r.verify(w) == (want_ok, nbad, first)
+        assert np.array_equal(r.residuals(w), want_res)
+        h, ok = r.qap_h(w)
+        want_h = R.verification_witness(oracle_qap, want, p)
+        assert ok == want_ok and (acx.fr_to_ints(h) if ok else None) == want_h

@@ -192,3 +192,21 @@ def test_mgpu_argument_errors(acx, request):
     assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
     mr.close()
     mr2.close()
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0,0,0"])
+def test_plain_c_host_drives_several_shards_without_rccl_or_hip_in_the_host(acx, request, tmp_path, devices):
+    """examples/mgpu_host.c: a plain-C program (gcc, include/acx.h only: no RCCL, HIP or Python in the host) runs
+    verifyAssignment and verificationWitness over the shards of an acx_mgpu handle and compares with the single-GPU
+    entry points; with "0" the exchange and the verdict go through real RCCL calls inside libacx."""
+    import os, subprocess
+    _mg(acx, request, "bn254", [0])
+    root = os.path.join(os.path.dirname(__file__), "..")
+    libdir = os.path.abspath(os.path.join(root, "arithmetic-circuits_amd"))
+    exe = str(tmp_path / "mgpu_host")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "mgpu_host.c"),
+                    "-L", libdir, "-lacx", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe],
+                   check=True, capture_output=True, text=True)
+    out = subprocess.run([exe, devices, "13"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "Valid assignment" in out.stdout, (out.stdout, out.stderr[-2000:])
+    assert ("RCCL" if devices == "0" else "peer copies") in out.stdout
