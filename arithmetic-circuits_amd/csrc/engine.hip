@@ -115,6 +115,15 @@ struct acx_ctx {
     std::map<std::pair<uint32_t, int>, uint4*> tw_low;    // (log_n, inverse) -> omega_N^j, j < 1024
     std::map<std::tuple<uint32_t, uint64_t, int, uint32_t>, uint4*> tw_scaled;   // (log_m, count, inverse, log_n of folded 1/N)
     std::map<std::pair<uint32_t, int>, uint4*> tw_limbs;  // (log_m, inverse) -> omega_M^j, j < M/2, limb form (k_ntt_r4)
+    // closing-factor tables of the distributed steps in store order (k_dist_table): (log_n, log_r, world, rank, kind, coset base)
+    struct DistKey {
+        uint32_t log_n, log_r, world, rank; int kind; H256 base;
+        bool operator<(const DistKey& o) const {
+            return std::tie(log_n, log_r, world, rank, kind, base.l[0], base.l[1], base.l[2], base.l[3]) <
+                   std::tie(o.log_n, o.log_r, o.world, o.rank, o.kind, o.base.l[0], o.base.l[1], o.base.l[2], o.base.l[3]);
+        }
+    };
+    std::map<DistKey, uint4*> tw_dist;
     NttCfg ntt;
     bool small_coeff = true;                               // use the small-coefficient SELL form where a matrix allows it
     uint4* ntt_scratch = nullptr;                          // ping-pong buffer of the multi-pass NTT
@@ -726,6 +735,41 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
     return ACX_OK;
 }
 
+// A closing-factor table of one distributed step in STORE order (k_dist_table), cached per context.
+//   kind 0: forward step 0 (twiddle, times g^i2 when coset != null)      kind 1: inverse step 0 (twiddle with 1/N)
+//   kind 2: inverse step 1 of a coset transform (g^-(i1 C + i2); coset = 1/g)
+// 32 bytes per local element (64 MB per direction for a 2^24-point transform over 8 ranks): with 288 GB of HBM that buys one
+// product per element instead of two (two-level powers) and a coalesced table read instead of two dependent gathers.
+int get_dist_table(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int kind, const H256* coset, uint4** out) {
+    CtxLock lock(c->mu);
+    acx_ctx::DistKey key{log_n, log_r, world, rank, kind, coset ? *coset : H256{{0, 0, 0, 0}}};
+    auto it = c->tw_dist.find(key);
+    if (it != c->tw_dist.end()) { *out = it->second; return ACX_OK; }
+    const uint64_t L = (1ull << log_n) / world;
+    DistTable T{};
+    T.log_n = log_n; T.log_r = log_r; T.rank = rank; T.inverse = kind == 1 ? 1u : 0u; T.cols_layout = kind == 2 ? 1u : 0u;
+    T.log_w = ilog2(world);
+    if (kind != 2) {
+        uint4 *lo = nullptr, *hi = nullptr;
+        ACX_TRY(get_scaled_table(c, log_n, 1024, kind == 1, kind == 1 ? log_n : 0, &lo));
+        if (log_n > 10) ACX_TRY(get_pow_table(c, log_n - 10, kind == 1, &hi));
+        T.w_lo = lo; T.w_hi = hi;
+    }
+    if (coset) {
+        uint4 *lo = nullptr, *hi = nullptr;
+        ACX_TRY(get_coset_tables(c, *coset, log_n, 0, &lo, &hi));
+        T.g_lo = lo; T.g_hi = hi;
+    }
+    uint4* tw = nullptr;
+    HIP_TRY(hipMalloc((void**)&tw, L * 32));
+    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_dist_table<F>), dim3(grid_for(c, L)), dim3(kBlock), 0, cur_stream(c), T, tw, L));
+    const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(cur_stream(c));
+    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(tw); HIP_TRY(e1); HIP_TRY(e2); }
+    c->tw_dist[key] = tw;
+    *out = tw;
+    return ACX_OK;
+}
+
 // ---- local steps of the distributed four-step transform ------------------------------
 // N = R*C, index split i = i1*C + i2, k = k1 + k2*R; W ranks; rank g owns the i2 block g (i side) and the k1
 // block g (k side).  Local layouts (N/W dev elements each):
@@ -793,28 +837,31 @@ int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t wo
         Q.c_iw = 1; Q.i_base = (uint64_t)rank * cw;                       // I = i2 (coset exponent only)
     }
     Q.n_outer = Q.outer[0].count > 1 ? 1 : 0;
-    if (twiddle_here) {
-        const uint32_t fold = inverse ? log_n : 0;                         // 1/N of the inverse transform rides on the twiddles
-        if (log_n <= std::max<uint32_t>(cfg.direct_tw, 16)) {
-            uint4* tw = nullptr;
-            ACX_TRY(get_scaled_table(c, log_n, N, inverse, fold, &tw));
-            Q.tw_mode = 1; Q.tw_lo = tw; Q.tw_shift = 0;
-        } else {
-            uint4 *lo = nullptr, *hi = nullptr;
-            ACX_TRY(get_scaled_table(c, log_n, 1024, inverse, fold, &lo));
-            ACX_TRY(get_pow_table(c, log_n - 10, inverse, &hi));
-            Q.tw_mode = 2; Q.tw_lo = lo; Q.tw_hi = hi; Q.tw_mask = N - 1;
-        }
-    }
     Q.scale = dev_arg(hf, hf.one());
-    if (shift_mont && ((!inverse && step == 0) || (inverse && step == 1))) {
-        // coset factor s^i (forward, on load) / s^-i (inverse, closing), i = i1*C + i2: digit i1, column i2
-        const H256 base = inverse ? hf.inv(*shift_mont) : *shift_mont;
-        uint4 *lo = nullptr, *hi = nullptr;
-        ACX_TRY(get_coset_tables(c, base, log_n, 0, &lo, &hi));
-        Q.sc_lo = lo; Q.sc_hi = hi;
-        Q.e_mode = 1; Q.e_t = C; Q.e_c = 1;
-        if (inverse) Q.scale_mode = 2; else Q.scale_on_load = 1;
+    // Closing factors come from rank-local tables in store order (get_dist_table): the twiddle w_N^(+-i2 k1) of step 0 (1/N of
+    // an inverse transform folded in), and the coset factor.  The factor s^i of a forward coset transform, i = i1 C + i2,
+    // splits: (s^C)^i1 depends on the transform digit only and is taken on load from a table of R entries; s^i2 is constant
+    // along a column, commutes with the column's transform and rides on the store-side table.  The factor s^-i of an inverse
+    // coset transform is the closing multiplication of its last step.
+    const bool coset = shift_mont != nullptr;
+    if (twiddle_here) {
+        uint4* tw = nullptr;
+        const H256* g = (!inverse && coset) ? shift_mont : nullptr;
+        ACX_TRY(get_dist_table(c, log_n, log_r, world, rank, inverse ? 1 : 0, g, &tw));
+        Q.tw_mode = 3; Q.tw_lo = tw;
+        if (g) {
+            // (s^C)^d for d < R: a direct table of the coset cache (base s^C, R entries)
+            const H256 sC = hf.pow_u64(*shift_mont, C);
+            uint4 *lo = nullptr, *hi = nullptr;
+            ACX_TRY(get_coset_tables(c, sC, log_r, 0, &lo, &hi, 1));          // direct: all 2^log_r powers
+            Q.sc_lo = lo; Q.sc_hi = nullptr;
+            Q.scale_on_load = 2;
+        }
+    } else if (inverse && coset) {
+        const H256 ginv = hf.inv(*shift_mont);
+        uint4* tw = nullptr;
+        ACX_TRY(get_dist_table(c, log_n, log_r, world, rank, 2, &ginv, &tw));
+        Q.tw_mode = 3; Q.tw_lo = tw;
     }
     const uint64_t tiles = cols / T;
     const bool ok = launch_ntt_r4(c->field == ACX_FIELD_BLS12_381_FR, lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
@@ -1363,6 +1410,7 @@ void acx_ctx_destroy(acx_ctx* c) {
     for (auto& kv : c->tw_low) (void)hipFree(kv.second);
     for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
     for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
+    for (auto& kv : c->tw_dist) (void)hipFree(kv.second);
     if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
     for (auto& e : c->cosets) { if (e.lo) (void)hipFree(e.lo); if (e.hi) (void)hipFree(e.hi); }
     c->cosets.clear();
@@ -1394,6 +1442,8 @@ int acx_ctx_set_root(acx_ctx* c, uint32_t two_adicity, const acx_fr* omega) {
     for (auto& kv : c->tw_low) (void)hipFree(kv.second);
     for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
     for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
+    for (auto& kv : c->tw_dist) (void)hipFree(kv.second);
+    c->tw_dist.clear();
     c->twiddles.clear();
     c->tw_low.clear();
     c->tw_scaled.clear();

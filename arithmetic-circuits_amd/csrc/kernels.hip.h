@@ -630,6 +630,45 @@ __global__ __launch_bounds__(kBlock) void k_pow_table_limbs(uint4* __restrict__ 
     }
 }
 
+// Closing-factor table of one local step of the distributed four-step transform, in the step's STORE order (k_ntt_r4
+// tw_mode 3): out[off] = first * w^(e1(off)) * g^(e2(off)), both powers from two-level tables (null = factor absent).
+//   XCHG layout (step 0: the twiddle w_N^(+-i2 k1), and g^i2 of a forward coset transform):
+//       off = (peer * rw + kl) * cw + i2l;  forward: k1 = peer * rw + kl, i2 = rank * cw + i2l;  inverse: k1 = rank * rw + kl, i2 = peer * cw + i2l
+//   COLS layout (inverse step 1: the coset factor g^-(i1 C + i2)):  off = i2l * R + i1, i2 = rank * cw + i2l
+struct DistTable {
+    const uint4 *w_lo, *w_hi;      // w_N^(+-j), j < 1024 (with 1/N folded in for an inverse transform) and w_N^(+-1024 j); null: no twiddle
+    const uint4 *g_lo, *g_hi;      // g^j, g^(1024 j) (or powers of 1/g); null: no coset factor
+    u32 log_n, log_r, log_w, rank;
+    u32 inverse, cols_layout;
+};
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_dist_table(DistTable T, uint4* __restrict__ out, u64 count) {
+    const u32 log_c = T.log_n - T.log_r, log_rw = T.log_r - T.log_w, log_cw = log_c - T.log_w;
+    const u64 mask = (1ull << T.log_n) - 1;
+    for (u64 off = (u64)blockIdx.x * kBlock + threadIdx.x; off < count; off += (u64)gridDim.x * kBlock) {
+        u64 e_w = 0, e_g = 0;
+        if (T.cols_layout) {
+            const u64 i1 = off & ((1ull << T.log_r) - 1), i2 = ((u64)T.rank << log_cw) + (off >> T.log_r);
+            e_g = (i1 << log_c) + i2;
+        } else {
+            const u64 i2l = off & ((1ull << log_cw) - 1), kl = (off >> log_cw) & ((1ull << log_rw) - 1), peer = off >> (log_cw + log_rw);
+            const u64 k1 = T.inverse ? (((u64)T.rank << log_rw) + kl) : ((peer << log_rw) + kl);
+            const u64 i2 = T.inverse ? ((peer << log_cw) + i2l) : (((u64)T.rank << log_cw) + i2l);
+            e_w = (i2 * k1) & mask;
+            e_g = i2;
+        }
+        Fe f;
+        bool have = false;
+        if (T.w_lo != nullptr) { f = two_level_pow<F>(T.w_lo, T.w_hi, e_w); have = true; }
+        if (T.g_lo != nullptr) {
+            const Fe g = two_level_pow<F>(T.g_lo, T.g_hi, e_g);
+            f = have ? fe_mul<F>(f, g) : g;
+            have = true;
+        }
+        fe_store(out + 2 * off, have ? f : fe_one_mont<F>());
+    }
+}
+
 // ---- K3/K4: tiled multi-pass NTT (pass descriptor and planning constants: ntt_pass.hip.h) ----------
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_ntt_tile(NttPass P) {

@@ -167,9 +167,15 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
 #pragma unroll 1
             for (u32 e = 0; e < 4; ++e) {
                 const u32 d = (rev2(e) << (ls - 2)) | dlow;
-                const u64 off = cbase + (u64)(d & smask) * P.stride_t_in + (u64)(d >> P.split_in) * P.stride_t_in_hi;
-                const u64 ex = P.e_mode ? (P.e_base + (u64)d * P.e_t + (P.i_base + I0 + (u64)col * P.c_iw) * P.e_c) : (off & P.idx_mask);
-                const Fe y = fe_mul<F>(x[0], two_level_pow<F>(P.sc_lo, P.sc_hi, ex));
+                Fe f;
+                if (P.scale_on_load == 2) {  // by the transform digit alone, from a direct table of S entries (distributed steps)
+                    f = fe_load(P.sc_lo + 2 * (u64)d);
+                } else {
+                    const u64 off = cbase + (u64)(d & smask) * P.stride_t_in + (u64)(d >> P.split_in) * P.stride_t_in_hi;
+                    const u64 ex = P.e_mode ? (P.e_base + (u64)d * P.e_t + (P.i_base + I0 + (u64)col * P.c_iw) * P.e_c) : (off & P.idx_mask);
+                    f = two_level_pow<F>(P.sc_lo, P.sc_hi, ex);
+                }
+                const Fe y = fe_mul<F>(x[0], f);
                 x[0] = x[1]; x[1] = x[2]; x[2] = x[3]; x[3] = y;
             }
         }
@@ -239,7 +245,9 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
                         (u64)(kd >> P.split_out) * P.stride_t_out_hi + (u64)col * P.stride_c_out;
         Fe f = scale;
         bool mul = true;
-        if (P.tw_mode == 1) {
+        if (P.tw_mode == 3) {                                // the closing factor of every element from a table in STORE order
+            f = fe_load(P.tw_lo + 2 * off);
+        } else if (P.tw_mode == 1) {
             const u64 K = P.k_base + K0 + (u64)kd * P.t_kw + (u64)col * P.c_kw, I = P.i_base + I0 + (u64)col * P.c_iw;
             f = fe_load(P.tw_lo + 2 * ((I * K) >> P.tw_shift));
         } else if (P.tw_mode == 2 || P.scale_mode == 2) {

@@ -95,13 +95,13 @@ def _valu_issue(key, count_field, us, workload):
     """VALU-issue fraction of a kernel: SQ_INSTS_VALU (wave instructions per launch, from the committed rocprofv3 --pmc
     pass of the same workload) / 1024 SIMDs / the measured multiplier issue rate, over the live launch time."""
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
         if tr[key]["workload"] != workload:
             return None
         rate = tr["valu_rate"]
         bound_us = tr[key][count_field] / rate["simds"] / rate["wave_insts_per_s_per_simd"] * 1e6
         return {"wave_insts": tr[key][count_field], "issue_bound_us": bound_us, "frac": bound_us / us,
-                "source": "profiles/r02_bench.txt, profiles/r01_valu_rates.txt"}
+                "source": "profiles/r03_traffic.json, profiles/r01_valu_rates.txt", "measured_in_run": False}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -562,6 +562,18 @@ def main():
     neg_batch.verify_dev()
     ctx.sync()
     assert int(neg[0]) > 0, "a corrupted witness was accepted"
+    # ... and not merely "something was caught": system 0's whole residual vector, violated-row count and first violated
+    # row under that corrupted witness against the CPU oracle, and the batched launch's count against the oracle's
+    parity_residuals = None
+    if rank == 0:
+        from oracle.c_oracle import COracle
+        mats0, w0, n0, m0 = sample
+        w0b = w0.copy()
+        w0b[77, 0] ^= np.uint64(1)
+        want_res, want_bad, want_first = COracle(a.field).r1cs_residuals(n0, m0, *mats0, w0b, nthreads=os.cpu_count() or 1)
+        parity_residuals = bool(want_bad > 0 and int(neg[0]) == want_bad and np.array_equal(systems[0].residuals(w0b), want_res)
+                                and systems[0].verify(w0b) == (False, want_bad, want_first))
+        assert parity_residuals, "residual vector of the corrupted system differs from the oracle's"
 
     # for reference: ONE 2^16-constraint system per launch (configs[1] taken literally; cache resident)
     single_us = None
@@ -594,7 +606,7 @@ def main():
             "metric": "R1CS constraints/sec (verifyAssignment over %s Fr, bit-exact vs oracle)" % ("BN254" if a.field == "bn254" else "BLS12-381"),
             "value": value, "unit": "constraints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u256 (9x29-bit limbs, Montgomery)", "data": "synthetic",
+            "dtype": "u256 (9x29-bit limbs, Montgomery)", "data": "synthetic", "parity_vs_oracle": parity_residuals,
             "launcher": "one process per GPU (torch.distributed.run), collectives through torch.distributed/RCCL" if use_dist else "single process, one GPU",
             "config": {"workload": f"r1cs_verify: {a.copies} independent 2^{a.logn}-constraint mulgraph systems per GPU per "
                                    f"step, one batched launch (k=2, n_in=1024, window=4096, seeds 0xAC355+1000*rank+c)",
@@ -614,10 +626,18 @@ def main():
                                 "frac_median": bytes_per_launch / bs[len(bs) // 2] * 1e-3 / HBM_PEAK_GBS,
                                 "note": "kernel times at the sustained clock (0.25 s untimed pre-run before the timed region)"}
         try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["acx::k_r1cs_sell"]
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))["acx::k_r1cs_sell"]
             if tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
+                # NOT measured in this run: a constant from the committed rocprofv3 --pmc pass of the same command (PMC
+                # counters need the profiler around the process).  The live quantities of this line are the times.
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_measured_in_run"] = False
                 out["roofline"]["traffic_source"] = tr["source"]
+                out["roofline"]["traffic_measured_at_commit"] = tr.get("measured_at_commit")
+                # the same launch time against the bytes the kernel really moves (the algorithmic figure counts 36 bytes
+                # per C entry that the unit-C path never reads, and 36 instead of 40 per A / B entry)
+                out["roofline"]["achieved_traffic"] = tr["traffic_bytes_per_launch"] / kernel_us * 1e-3
+                out["roofline"]["frac_traffic"] = out["roofline"]["achieved_traffic"] / HBM_PEAK_GBS
                 out["roofline"]["valu_issue"] = _valu_issue("acx::k_r1cs_sell", "valu_wave_insts_per_launch", kernel_us, tr["workload"])
         except (OSError, KeyError, ValueError):
             pass
