@@ -895,16 +895,13 @@ inline int sell_spec_join(int a, int b) { return a == b ? a : 2; }
 // grid.x is sized by sell_grid_x for the launch's largest system: one workgroup (two waves) per slice.
 inline void launch_sell(acx_ctx* c, int spec, dim3 grid, const SellSystem* systems, const SellSystem& one) {
     DISPATCH_FIELD(c, {
-        if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell_split<F, 0>), grid, dim3(2 * kSlice * kK2Slices), 0, cur_stream(c), systems, one);
-        else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell_split<F, 1>), grid, dim3(2 * kSlice * kK2Slices), 0, cur_stream(c), systems, one);
-        else hipLaunchKernelGGL((k_r1cs_sell_split<F, 2>), grid, dim3(2 * kSlice * kK2Slices), 0, cur_stream(c), systems, one);
+        if (spec == 0) hipLaunchKernelGGL((k_r1cs_sell_split<F, 0>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
+        else if (spec == 1) hipLaunchKernelGGL((k_r1cs_sell_split<F, 1>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
+        else hipLaunchKernelGGL((k_r1cs_sell_split<F, 2>), grid, dim3(2 * kSlice), 0, cur_stream(c), systems, one);
     });
 }
 
-inline unsigned sell_grid_x(uint32_t n_slices) {          // workgroups, a multiple of 8: the XCD remap is a bijection
-    const uint32_t tiles = (n_slices + kK2Slices - 1) / kK2Slices;
-    return ((tiles + 7) / 8) * 8;
-}
+inline unsigned sell_grid_x(uint32_t n_slices) { return ((n_slices + 7) / 8) * 8; }   // multiple of 8: the XCD remap is a bijection
 
 // rows too long for SELL go through the CSR kernel
 int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out, const SellSystem* d_many = nullptr, uint32_t n_many = 1) {

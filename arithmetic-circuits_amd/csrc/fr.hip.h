@@ -194,47 +194,6 @@ __device__ __forceinline__ Fe fe_mul(const Fe& a, const Fe& b) {
     return r;
 }
 
-// Montgomery product by a TABLE CONSTANT with a precomputed companion (the butterfly twiddles of the NTT): for a constant
-// w the quotient digits m = (x w mod R) * N' mod R (N' = -p^-1 mod R, F::NP) equal x * w'' mod R with w'' = w N' mod R stored
-// beside w.  So m is ONE low-half product (columns 0..8 of x w'': 45 multiplier instructions, independent of x w), and
-// the result (x w + m p) / R needs only the HIGH columns of the two products: the low halves sum to an exact multiple
-// of R, so their contribution to column 9 is the integer nearest to (T_8 2^232 + T_7 2^203) / 2^261 -- columns 0..6 carry
-// less than 2^-20 of a unit -- i.e. columns 7..16 of x w and of m p (53 each).  151 multiplier instructions against the
-// 171 (162 v_mad_u64_u32 + 9 v_mul_lo_u32) of fe_mul, no dependent chain from the product into the quotient digits.
-// x: loose or uncarried (limbs < 2^31, value < 64 p); w: CANONICAL (< p) with strict limbs, wpp = w * NP mod R (strict limbs).
-// Result: strict limbs, value < 2p (x w / R + p < (64 p / R + 1) p, p / R < 2^-6.1 for both fields).
-// Checked against big integers by a bit-accurate model before it was written (tools/model_mul_pre.py).
-template <class F>
-__device__ __forceinline__ Fe fe_mul_pre(const Fe& x, const Fe& w, const Fe& wpp) {
-    u32 m[kLimbs];
-    {
-        u64 t = 0;
-#pragma unroll
-        for (int k = 0; k < kLimbs; ++k) {
-#pragma unroll
-            for (int i = 0; i <= k; ++i) t += (u64)x.l[i] * wpp.l[k - i];
-            m[k] = (u32)t & kLimbMask;
-            t >>= kLimbBits;
-        }
-    }
-    u64 t7 = 0, t8 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t7 += (u64)x.l[i] * w.l[7 - i] + (u64)m[i] * F::P[7 - i];
-#pragma unroll
-    for (int i = 0; i < kLimbs; ++i) t8 += (u64)x.l[i] * w.l[8 - i] + (u64)m[i] * F::P[8 - i];
-    u64 t = ((t8 + (t7 >> kLimbBits)) + (1ull << (kLimbBits - 1))) >> kLimbBits;     // the low halves' exact carry
-    Fe r;
-#pragma unroll
-    for (int k = kLimbs; k < 2 * kLimbs - 1; ++k) {
-#pragma unroll
-        for (int i = k - kLimbs + 1; i < kLimbs; ++i) t += (u64)x.l[i] * w.l[k - i] + (u64)m[i] * F::P[k - i];
-        r.l[k - kLimbs] = (u32)t & kLimbMask;
-        t >>= kLimbBits;
-    }
-    r.l[kLimbs - 1] = (u32)t;
-    return r;
-}
-
 // ---- lazy butterfly arithmetic (NTT) ---------------------------------------------------------------
 // "Loose" values: limbs < 2^29 + 8 (top limb free), value < 64p (fits 261 bits for both fields).
 // fe_mul accepts a loose left operand when the right operand is strictly normalised and < 2p

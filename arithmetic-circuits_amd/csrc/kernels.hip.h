@@ -9,24 +9,6 @@ namespace acx {
 
 constexpr int kBlock = 256;
 
-#ifdef ACX_K2_WAVES
-#define ACX_K2_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ACX_K2_WAVES, ACX_K2_WAVES)))
-#else
-#define ACX_K2_WAVES_ATTR
-#endif
-#ifndef ACX_K2_PIPE
-#define ACX_K2_PIPE 0          // development A/B switch of the residual kernel's software pipeline (profiles/r03_r1cs.txt)
-#endif
-#ifndef ACX_K2_NOPEEL
-#define ACX_K2_NOPEEL 0
-#endif
-#ifndef ACX_K2_HOT
-#define ACX_K2_HOT 0           // A/B: the first ACX_K2_HOT wires (constant + inputs) served from an LDS copy, four slices per workgroup
-#endif
-#ifndef ACX_K2_LAYOUT
-#define ACX_K2_LAYOUT 0        // A/B: 1 = packed 32-byte values + 4-byte column stream (36 bytes per entry, 4 per unit-C entry)
-#endif
-
 // Device CSR view (values in dev format: 2 x uint4 per entry).
 struct CsrDev {
     const u32* rowptr;
@@ -129,17 +111,9 @@ __global__ __launch_bounds__(kBlock) void k_build_sell(CsrDev M, const u32* __re
         Fe v = fe_zero();
         u32 c = kNoRow;
         if (j < len) { v = fe_load(M.val + 2 * (u64)(e0 + j)); c = M.col[e0 + j]; }
-#if ACX_K2_LAYOUT == 1
-        ((u32*)tail)[(u64)q * kSlice + lane] = c;
-        u32 pw[8];
-        fe_pack(v, pw);
-        val[(2 * (u64)q) * kSlice + lane] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-        val[(2 * (u64)q + 1) * kSlice + lane] = make_uint4(pw[4], pw[5], pw[6], pw[7]);
-#else
         tail[(u64)q * kSlice + lane] = make_uint2(v.l[8], c);
         val[(2 * (u64)q) * kSlice + lane] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
         val[(2 * (u64)q + 1) * kSlice + lane] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-#endif
     }
 }
 
@@ -183,50 +157,15 @@ __global__ __launch_bounds__(kBlock) void k_build_sell_small(CsrDev M, const u32
     }
 }
 
-// where a witness element comes from: global memory, or (ACX_K2_HOT) the workgroup's LDS copy of the first wires
-typedef __attribute__((address_space(3))) const v4u32 lds_v4u32;
-struct WitSrc {
-    const uint4* w;
-#if ACX_K2_HOT
-    lds_v4u32* hot;            // [2][ACX_K2_HOT]: low halves, high halves
-#endif
-};
-__device__ __forceinline__ void wit_load(const WitSrc& G, u32 c, uint4& lo, uint4& hi) {
-#if ACX_K2_HOT
-    if (c < (u32)ACX_K2_HOT) {
-        const v4u32 a = G.hot[c], b = G.hot[ACX_K2_HOT + c];
-        lo = make_uint4(a.x, a.y, a.z, a.w);
-        hi = make_uint4(b.x, b.y, b.z, b.w);
-        return;
-    }
-#endif
-    const uint4* px = G.w + 2 * (u64)c;
-    lo = gload(px);
-    hi = gload(px + 1);
-}
-__device__ __forceinline__ u32 nt_load(const u32* p) { return __builtin_nontemporal_load((g_u32*)p); }
-// column of SELL slot q of this lane (kNoRow = padding) in either stream layout
-__device__ __forceinline__ u32 sell_col(const SellDev& M, u32 q, u32 lane) {
-#if ACX_K2_LAYOUT == 1
-    return nt_load((const u32*)M.tail + (u64)q * kSlice + lane);
-#else
-    return gload(&M.tail[(u64)q * kSlice + lane]).y;
-#endif
-}
-
 template <class F, bool UNIT>
-__device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 slice, u32 lane) {
-    const uint4* __restrict__ w = G.w;
+__device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane) {
     const u32 q0 = sload(M.slice_ofs + slice), q1 = sload(M.slice_ofs + slice + 1);   // wave-uniform: scalar loads
     Fe acc = fe_zero();
     if (UNIT) {
         for (u32 q = q0; q < q1; ++q) {
-            const u32 c = sell_col(M, q, lane);
+            const u32 c = gload(&M.tail[(u64)q * kSlice + lane]).y;
             if (c != kNoRow) {
-                uint4 xlo, xhi;
-                wit_load(G, c, xlo, xhi);
-                const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
-                const Fe x = fe_unpack(xw);
+                const Fe x = fe_gload(w + 2 * (u64)c);
                 acc = (q == q0) ? x : fe_add<F>(acc, x);    // rows are sorted: padding never precedes data
             }
         }
@@ -238,72 +177,19 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 sl
     // costs one L1 tag lookup per lane), not by VALU or HBM bytes.  So: the gather of slot q is
     // issued first, then the stream loads of slot q+1, and only the gather is waited for (vmcnt
     // retires in order), which keeps a value-stream request in flight during every multiply.
+    // Round 3 re-measured three levers on THIS kernel, same box, with counters (profiles/r03_r1cs.txt; the variants live in
+    // git history at 8562ec3): the gather one slot ahead as well (92-100 VGPRs: 5 / 4 waves per SIMD: +3 / +6 %), the first
+    // 1024 wires from an LDS copy (per-workgroup and persistent forms: +4 ... +9 %; L2 requests -17 %, time up), 36-byte
+    // entries with a 4-byte unit-C stream (HBM bytes -9.3 %, time unchanged).  None is kept.
     static_assert(kSellMaxLen <= kWideTerms, "a SELL row is reduced once");
     if (q0 == q1) return acc;
     Wide wide;
-#if ACX_K2_PIPE == 1
-    // Gather one slot AHEAD as well: in iteration q the gather of slot q+1 (its column arrived with the tail word loaded
-    // two slots ahead), the values of slot q+1 and the tail of slot q+2 are issued before the products of slot q, whose
-    // operands were requested a whole iteration earlier.
-    wide_zero(wide);
-    uint2 t0 = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
-    uint2 t1 = t0;
-    if (q0 + 1 < q1) t1 = nt_load(&M.tail[(u64)(q0 + 1) * kSlice + lane]);
-    uint4 lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
-    uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
-    const uint4* px = w + 2 * (u64)(t0.y == kNoRow ? 0u : t0.y);
-    uint4 xlo = gload(px), xhi = gload(px + 1);
-#pragma unroll 1
-    for (u32 q = q0; q < q1; ++q) {
-        Fe v;
-        v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
-        v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
-        v.l[8] = t0.x;
-        const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
-        const Fe x = fe_unpack(xw);
-        if (q + 1 < q1) {
-            const uint4* pn = w + 2 * (u64)(t1.y == kNoRow ? 0u : t1.y);
-            xlo = gload(pn);
-            xhi = gload(pn + 1);
-            lo = nt_load(&M.val[(2 * (u64)(q + 1)) * kSlice + lane]);
-            hi = nt_load(&M.val[(2 * (u64)(q + 1) + 1) * kSlice + lane]);
-            t0 = t1;
-            if (q + 2 < q1) t1 = nt_load(&M.tail[(u64)(q + 2) * kSlice + lane]);
-        }
-        wide_mac(wide, v, x);
-    }
-    return wide_reduce<F>(wide);
-#elif ACX_K2_LAYOUT == 1
-    // 36 bytes per entry: 4-byte column + the packed 256-bit value (limbs split in registers)
-    u32 col = sell_col(M, q0, lane);
-    uint4 lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
-    uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
-    for (u32 q = q0; q < q1; ++q) {
-        uint4 xlo, xhi;
-        wit_load(G, col == kNoRow ? 0u : col, xlo, xhi);
-        const u32 vw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (q + 1 < q1) {
-            col = sell_col(M, q + 1, lane);
-            lo = nt_load(&M.val[(2 * (u64)(q + 1)) * kSlice + lane]);
-            hi = nt_load(&M.val[(2 * (u64)(q + 1) + 1) * kSlice + lane]);
-        }
-        const Fe v = fe_unpack(vw);
-        const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
-        const Fe x = fe_unpack(xw);
-        if (q == q0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
-    }
-    return wide_reduce<F>(wide);
-#else
     uint2 t = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
     uint4 lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
     uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
-#if ACX_K2_NOPEEL
-    wide_zero(wide);
-#pragma unroll 1
-#endif
     for (u32 q = q0; q < q1; ++q) {
-        uint4 xlo, xhi;
-        wit_load(G, t.y == kNoRow ? 0u : t.y, xlo, xhi);             // padding: value 0 * w[0]
+        const uint4* px = w + 2 * (u64)(t.y == kNoRow ? 0u : t.y);   // padding: value 0 * w[0]
+        const uint4 xlo = gload(px), xhi = gload(px + 1);
         Fe v;
         v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
         v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
@@ -315,14 +201,9 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 sl
         }
         const u32 xw[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
         const Fe x = fe_unpack(xw);
-#if ACX_K2_NOPEEL
-        wide_mac(wide, v, x);
-#else
         if (q == q0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
-#endif
     }
     return wide_reduce<F>(wide);
-#endif
 }
 
 // <M_row, w> for a small-coefficient matrix: nine signed columns, one v_mad_i64_i32 per limb and entry, one exact
@@ -330,8 +211,7 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const WitSrc& G, u32 sl
 // pays here for a deeper pipeline: the column word of slot q+2 and the witness gather of slot q+1 are in flight while
 // slot q is accumulated.
 template <class F>
-__device__ __forceinline__ Fe sell_dot_small(const SellDev& M, const WitSrc& G, u32 slice, u32 lane) {
-    const uint4* __restrict__ w = G.w;
+__device__ __forceinline__ Fe sell_dot_small(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane) {
     const u32 q0 = sload(M.slice_ofs + slice), q1 = sload(M.slice_ofs + slice + 1);   // wave-uniform: scalar loads
     static_assert(kSellMaxLen <= kWideTerms, "column bound of small_reduce");
     if (q0 == q1) return fe_zero();
@@ -452,67 +332,34 @@ __device__ __forceinline__ SellSystem sell_system_of_launch(const SellSystem* sy
 // (the first form of this kernel, three waves with the closing test on the wave that finishes first, lost 15 % to that).
 // Same box, alternating processes (tools/k2_ab.py, bench workload, us per launch): one wave per slice 120.3, three waves
 // (A + closing | B | C) 118.1, two waves (A + closing | B, C) 115.2, this form 114.7.
-constexpr int kK2Slices = ACX_K2_HOT ? 4 : 1;          // slices per workgroup (two waves each)
 template <class F, int SPEC = 0>
-__global__ __launch_bounds__(2 * kSlice * kK2Slices) ACX_K2_WAVES_ATTR void k_r1cs_sell_split(const SellSystem* __restrict__ systems, SellSystem one) {
+__global__ __launch_bounds__(2 * kSlice) void k_r1cs_sell_split(const SellSystem* __restrict__ systems, SellSystem one) {
     const SellSystem S = sell_system_of_launch(systems, one);               // batched : single
-    const u32 tiles = (S.n_slices + kK2Slices - 1) / kK2Slices;
-    const u32 per_xcd = (tiles + 7) / 8;
-    const u32 tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (blockIdx.x >= 8 * per_xcd || tile >= tiles) return;                // uniform over the workgroup
-    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kSlice), lane = threadIdx.x % kSlice;
-    const u32 sl = wave >> 1, wv = wave & 1u;
-    const u32 slice = tile * kK2Slices + sl;
+    const u32 per_xcd = (S.n_slices + 7) / 8;
+    const u32 slice = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (blockIdx.x >= 8 * per_xcd || slice >= S.n_slices) return;          // uniform over the workgroup
+    const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kSlice), lane = threadIdx.x % kSlice;
     constexpr bool kMixed = SPEC == 2;
-    __shared__ u32 park[kK2Slices][2][kLimbs][kSlice];
-    WitSrc G;
-    G.w = S.w;
-#if ACX_K2_HOT
-    // the workgroup's copy of the first wires (constant, inputs): half of the bench circuit's gathers, and they stop
-    // competing with the constraint stream for the vector L1
-    __shared__ v4u32 hot[2 * ACX_K2_HOT];
-    __shared__ u32 ready[kK2Slices];
-    for (u32 i = threadIdx.x; i < 2u * ACX_K2_HOT; i += 2 * kSlice * kK2Slices) {
-        const uint4 x = gload(S.w + i);
-        v4u32 y; y.x = x.x; y.y = x.y; y.z = x.z; y.w = x.w;
-        hot[(i & 1u) * ACX_K2_HOT + (i >> 1)] = y;
-    }
-    if (threadIdx.x < kK2Slices) ready[threadIdx.x] = 0;
-    __syncthreads();
-    G.hot = (lds_v4u32*)hot;
-    if (slice >= S.n_slices) return;                                       // whole waves; no workgroup barrier follows
-#endif
+    __shared__ u32 park[2][kLimbs][kSlice];
     Fe b = fe_zero(), c = b;
     u32 row = kNoRow;
     if (wv == 0) {
-        const Fe a = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, G, slice, lane) : sell_dot<F, false>(S.A, G, slice, lane);
+        const Fe a = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
 #pragma unroll
-        for (int i = 0; i < kLimbs; ++i) park[sl][0][i][lane] = a.l[i];
+        for (int i = 0; i < kLimbs; ++i) park[0][i][lane] = a.l[i];
     } else {
         row = gload(S.perm + slice * kSlice + lane);                        // needed last: issued first
-        b = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, G, slice, lane) : sell_dot<F, false>(S.B, G, slice, lane);
+        b = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
 #pragma unroll
-        for (int i = 0; i < kLimbs; ++i) park[sl][1][i][lane] = b.l[i];     // own wave's LDS traffic is ordered: no barrier
-        c = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, G, slice, lane)
-            : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, G, slice, lane) : sell_dot<F, false>(S.C, G, slice, lane);
+        for (int i = 0; i < kLimbs; ++i) park[1][i][lane] = b.l[i];         // own wave's LDS traffic is ordered: no barrier
+        c = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
+            : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
     }
-#if ACX_K2_HOT
-    // pair synchronisation through LDS (a workgroup barrier would tie the four slices together): wave 0 publishes, wave 1 --
-    // the one with the longer job -- usually finds the flag set
-    if (wv == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) *(volatile u32*)&ready[sl] = 1u;
-        return;
-    }
-    while (*(volatile u32*)&ready[sl] == 0u) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#else
     __syncthreads();
     if (wv == 0) return;
-#endif
     Fe a;
 #pragma unroll
-    for (int i = 0; i < kLimbs; ++i) { a.l[i] = park[sl][0][i][lane]; b.l[i] = park[sl][1][i][lane]; }
+    for (int i = 0; i < kLimbs; ++i) { a.l[i] = park[0][i][lane]; b.l[i] = park[1][i][lane]; }
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
 }
 
@@ -604,29 +451,15 @@ __global__ __launch_bounds__(kBlock) void k_pow_table_scaled(uint4* __restrict__
         fe_store(tw + 2 * j, fe_mul<F>(fe_pow<F>(base, j), first));
 }
 
-// limb-form table for k_ntt_r4: entry j = 5 x uint4 = the nine 29-bit limbs of w = base^j (CANONICAL: fe_mul_pre's bound
-// needs w < p) followed by the nine limbs of w'' = w * NP mod R (fe_mul_pre's precomputed quotient factor); no unpacking
-// in the kernel
+// limb-form table for k_ntt_r4: entry j = 3 x uint4 holding the nine 29-bit limbs of base^j (no unpacking in the kernel)
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_pow_table_limbs(uint4* __restrict__ tw, u64 count, FeArg base_arg) {
     const Fe base = fe_from_arg(base_arg);
     for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < count; j += (u64)gridDim.x * kBlock) {
-        const Fe w = fe_reduce<F>(fe_pow<F>(base, j));
-        u32 q[kLimbs];
-        u64 t = 0;
-#pragma unroll
-        for (int k = 0; k < kLimbs; ++k) {                       // low half of w * NP
-#pragma unroll
-            for (int i = 0; i <= k; ++i) t += (u64)w.l[i] * F::NP[k - i];
-            q[k] = (u32)t & kLimbMask;
-            t >>= kLimbBits;
-        }
-        uint4* e = tw + kLimbEntryQuads * j;
-        e[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
-        e[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
-        e[2] = make_uint4(w.l[8], q[0], q[1], q[2]);
-        e[3] = make_uint4(q[3], q[4], q[5], q[6]);
-        e[4] = make_uint4(q[7], q[8], 0u, 0u);
+        const Fe w = fe_pow<F>(base, j);
+        tw[kLimbEntryQuads * j] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
+        tw[kLimbEntryQuads * j + 1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
+        tw[kLimbEntryQuads * j + 2] = make_uint4(w.l[8], 0u, 0u, 0u);
     }
 }
 

@@ -5,7 +5,7 @@
 
 namespace acx {
 
-constexpr int kLimbEntryQuads = 5;     // uint4 words per entry of a limb-form twiddle table (k_pow_table_limbs)
+constexpr int kLimbEntryQuads = 3;     // uint4 words per entry of a limb-form twiddle table (k_pow_table_limbs): 9 limbs + padding
 
 // ---- K3/K4: tiled multi-pass NTT ---------------------------------------------------------------
 // A length-N transform is factored N = N_1 * ... * N_P (P <= 4, every N_p <= 256).  Pass p runs

@@ -1,9 +1,6 @@
-// ntt_r4.hip -- the instances of k_ntt_r4 (ntt_r4.hip.h) and their launcher, in a translation unit of their own:
-//   * it is compiled with `-mllvm -misched=gcn-iterative-minreg` (build.py): with the default scheduler the pass kernels sit
-//     at the 128-VGPR ceiling of a 1024-thread workgroup and the BLS12-381 instances spill; the register-minimising
-//     scheduler holds every instance spill-free at 120-126 VGPRs WITH fe_mul_pre's second table operand
-//     (tools/kres.sh, profiles/r03_ntt.txt);
-//   * the two translation units of libacx.so compile in parallel.
+// ntt_r4.hip -- the instances of k_ntt_r4 (ntt_r4.hip.h) and their launcher, in a translation unit of their own: the two
+// units of libacx.so compile in parallel (27 s instead of 74 s), and the pass kernels can be given their own device-side
+// LLVM options (build.py, ACX_NTT_MISCHED: how the scheduler experiments of profiles/r03_ntt.txt were built).
 #include <hip/hip_runtime.h>
 
 #include "field_consts.h"

@@ -25,10 +25,6 @@
 #pragma once
 #include "ntt_pass.hip.h"
 
-#ifndef ACX_NTT_PRE
-#define ACX_NTT_PRE 1          // butterfly products by table twiddles through fe_mul_pre (0: plain fe_mul; A/B switch)
-#endif
-
 namespace acx {
 
 __device__ __forceinline__ u32 rev2(u32 x) { return ((x & 1u) << 1) | (x >> 1); }
@@ -53,30 +49,17 @@ __device__ __forceinline__ Fe fe_reduce_loose(Fe a) {
     return fe_cond_sub<F::P2>(r);
 }
 
-// sub-transform twiddles in limb form: entry j = 5 x uint4 = the nine limbs of w_S^j (canonical) and of its quotient
-// factor w'' (k_pow_table_limbs); the products by them are fe_mul_pre (151 multiplier instructions instead of 171)
-struct Twiddle { Fe w, wpp; };
-__device__ __forceinline__ Twiddle fe_load_limbs(const uint4* __restrict__ tab, u64 idx) {
-    const uint4* e = tab + kLimbEntryQuads * idx;
-    const uint4 a = gload(e), b = gload(e + 1), c = gload(e + 2), d = gload(e + 3), f = gload(e + 4);
-    Twiddle r;
-    r.w.l[0] = a.x; r.w.l[1] = a.y; r.w.l[2] = a.z; r.w.l[3] = a.w;
-    r.w.l[4] = b.x; r.w.l[5] = b.y; r.w.l[6] = b.z; r.w.l[7] = b.w;
-    r.w.l[8] = c.x;
-    r.wpp.l[0] = c.y; r.wpp.l[1] = c.z; r.wpp.l[2] = c.w;
-    r.wpp.l[3] = d.x; r.wpp.l[4] = d.y; r.wpp.l[5] = d.z; r.wpp.l[6] = d.w;
-    r.wpp.l[7] = f.x; r.wpp.l[8] = f.y;
+// sub-transform twiddles in limb form: entry j = 3 x uint4 = the nine 29-bit limbs of w_S^j (strict) + padding.
+// (Round 3 tried a second table operand -- w'' = w * (-p^-1) mod R, which turns the product into 151 multiplier
+// instructions instead of 171: bit-exact, never faster, because the pass kernels sit at the 128-register ceiling of a
+// 1024-thread workgroup; profiles/r03_ntt.txt, code at commit 8562ec3, model tools/model_mul_pre.py.)
+__device__ __forceinline__ Fe fe_load_limbs(const uint4* __restrict__ tab, u64 idx) {
+    const uint4 a = gload(tab + kLimbEntryQuads * idx), b = gload(tab + kLimbEntryQuads * idx + 1), c = gload(tab + kLimbEntryQuads * idx + 2);
+    Fe r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x;
     return r;
-}
-// BN254 Fr takes fe_mul_pre; BLS12-381 Fr keeps fe_mul: its modulus has P[0] = 1 and N0 = -1, so fe_mul is already 152
-// multiplier instructions there, and the second table operand pushes its instances over the 128 registers a 1024-thread
-// workgroup may use (84-100 bytes of scratch per lane under either scheduler; tools/kres.sh, profiles/r03_ntt.txt).
-template <class F> struct TwiddlePre { static constexpr bool value = ACX_NTT_PRE != 0; };
-template <> struct TwiddlePre<Bls12381Fr> { static constexpr bool value = false; };
-template <class F>
-__device__ __forceinline__ Fe tw_mul(const Fe& x, const Twiddle& t) {
-    if constexpr (TwiddlePre<F>::value) return fe_mul_pre<F>(x, t.w, t.wpp);
-    else return fe_mul<F>(x, t.w);
 }
 
 // One round on the four slots: stage A pairs (0,1),(2,3) with twiddle wA, stage B pairs (0,2),(1,3) with
@@ -90,19 +73,19 @@ __device__ __forceinline__ void r4_round(Fe (&x)[4], const uint4* __restrict__ t
         if (TRIV) {
             t1 = fe_reduce_loose<F>(x[1]); t3 = fe_reduce_loose<F>(x[3]);
         } else {
-            const Twiddle w = fe_load_limbs(tw, iA);
-            t1 = tw_mul<F>(x[1], w); t3 = tw_mul<F>(x[3], w);
+            const Fe w = fe_load_limbs(tw, iA);
+            t1 = fe_mul<F>(x[1], w); t3 = fe_mul<F>(x[3], w);
         }
         const Fe a0 = fe_add_lazy<false>(x[0], t1), s0 = fe_sub_lazy<F, false>(x[0], t1);
         const Fe a1 = fe_add_lazy<false>(x[2], t3), s1 = fe_sub_lazy<F, false>(x[2], t3);
         x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
     }
     if (stage_b) {
-        const Twiddle w1 = fe_load_limbs(tw, iB1);
+        const Fe w1 = fe_load_limbs(tw, iB1);
         Fe t2;
         if (TRIV) t2 = fe_reduce_loose<F>(x[2]);
-        else t2 = tw_mul<F>(x[2], fe_load_limbs(tw, iB0));
-        const Fe t3 = tw_mul<F>(x[3], w1);
+        else t2 = fe_mul<F>(x[2], fe_load_limbs(tw, iB0));
+        const Fe t3 = fe_mul<F>(x[3], w1);
         const Fe a0 = fe_add_lazy(x[0], t2), s0 = fe_sub_lazy<F>(x[0], t2);
         const Fe a1 = fe_add_lazy(x[1], t3), s1 = fe_sub_lazy<F>(x[1], t3);
         x[0] = a0; x[2] = s0; x[1] = a1; x[3] = s1;
@@ -189,7 +172,7 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
         if (!(R == 1 && odd)) {
             // pair (0,2): w = 1 and x[2] is the uncarried sum of two strict values: it is subtracted as it is, against
             // the fat form of 8p (value grows by 8p once per pass: 12p after this round, < 64p after 12 stages)
-            const Fe t3 = tw_mul<F>(x[3], fe_load_limbs(P.sub_tw, (u64)(S >> 2)));
+            const Fe t3 = fe_mul<F>(x[3], fe_load_limbs(P.sub_tw, (u64)(S >> 2)));
             const Fe b0 = fe_add_lazy(x[0], x[2]), d0 = fe_sub_fat<F::P8FAT>(x[0], x[2]);
             const Fe b1 = fe_add_lazy(x[1], t3), d1 = fe_sub_lazy<F>(x[1], t3);
             x[0] = b0; x[2] = d0; x[1] = b1; x[3] = d1;

@@ -6,6 +6,7 @@ set -e
 sig="$1"; shift
 d=$(mktemp -d)
 cat > $d/k.hip <<EOT
+#include "kernels.hip.h"
 #include "ntt_r4.hip.h"
 using namespace acx;
 template __global__ void $sig;
