@@ -782,8 +782,10 @@ int get_dist_table(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, u
 //           step 1  XCHG -> COLS  (length-R inverse transforms over k1, coset factor s^-i at the end)
 // Each step is ONE launch of k_ntt_r4: the transposes are strides of the pass descriptor, the twiddle is the
 // kernel's closing multiplication from tables -- no separate twiddle kernel, no permute copies.
+// rows_transposed (inverse step 0 only): the input is the ROWS block stored TRANSPOSED, [k2][kl] -- the ascending row order in
+// which the residual kernel of a block-cyclic shard writes its dot products (mgpu.inc.h) -- instead of [kl][k2].
 int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
-                         const H256* shift_mont, const uint4* in, uint4* out) {
+                         const H256* shift_mont, const uint4* in, uint4* out, bool rows_transposed = false) {
     const HostField& hf = c->hf;
     const NttCfg& cfg = c->ntt;
     if ((int)log_n > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
@@ -816,6 +818,8 @@ int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t wo
     Q.idx_mask = N - 1;
     const uint64_t chunk = rw * cw;
     const bool twiddle_here = step == 0;
+    bool xcd_outer = false;
+    if (rows_transposed && !(inverse && step == 0)) return fail(ACX_ERR_INVALID_ARG, "internal: transposed input is an inverse step 0 form");
     if (!inverse && step == 0) {            // COLS -> XCHG
         Q.stride_t_in = 1; Q.stride_t_in_hi = 1; Q.stride_c_in = R;
         Q.stride_t_out = cw; Q.stride_t_out_hi = cw; Q.stride_c_out = 1;
@@ -825,6 +829,21 @@ int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t wo
         Q.split_in = ilog2(cw); Q.stride_t_in = 1; Q.stride_t_in_hi = chunk; Q.stride_c_in = cw;
         Q.stride_t_out = 1; Q.stride_t_out_hi = 1; Q.stride_c_out = C;
         Q.outer[0] = NttOuter{(u32)(cols / T), 0, T * cw, T * C, 0, 0};
+    } else if (step == 0 && rows_transposed) {     // ROWS^T [k2][kl] -> XCHG
+        // The transform direction has stride rw and a column is 32 bytes wide, so four neighbouring columns share every
+        // 128-byte line.  Tiles are therefore numbered XCD-first (workgroup b runs on XCD b % 8): an XCD's consecutive
+        // workgroups take NEIGHBOURING columns, and a line is fetched from HBM into one L2 once, not into four.
+        Q.stride_t_in = rw; Q.stride_t_in_hi = rw; Q.stride_c_in = 1;
+        Q.split_out = ilog2(cw); Q.stride_t_out = 1; Q.stride_t_out_hi = chunk; Q.stride_c_out = cw;
+        const uint64_t tiles_n = cols / T;
+        if (tiles_n % 8 == 0) {
+            Q.outer[0] = NttOuter{8u, 0, (tiles_n / 8) * T, (tiles_n / 8) * T * cw, 0, (tiles_n / 8) * T};
+            Q.outer[1] = NttOuter{(u32)(tiles_n / 8), 0, T, T * cw, 0, T};
+            xcd_outer = true;
+        } else {
+            Q.outer[0] = NttOuter{(u32)tiles_n, 0, T, T * cw, 0, T};
+        }
+        Q.t_kw = 1; Q.c_iw = 1; Q.i_base = (uint64_t)rank * rw;
     } else if (step == 0) {                 // ROWS -> XCHG
         Q.stride_t_in = 1; Q.stride_t_in_hi = 1; Q.stride_c_in = C;
         Q.split_out = ilog2(cw); Q.stride_t_out = 1; Q.stride_t_out_hi = chunk; Q.stride_c_out = cw;
@@ -836,7 +855,7 @@ int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t wo
         Q.outer[0] = NttOuter{(u32)(cols / T), 0, T, T * R, 0, T};
         Q.c_iw = 1; Q.i_base = (uint64_t)rank * cw;                       // I = i2 (coset exponent only)
     }
-    Q.n_outer = Q.outer[0].count > 1 ? 1 : 0;
+    Q.n_outer = xcd_outer ? 2 : (Q.outer[0].count > 1 ? 1 : 0);
     Q.scale = dev_arg(hf, hf.one());
     // Closing factors come from rank-local tables in store order (get_dist_table): the twiddle w_N^(+-i2 k1) of step 0 (1/N of
     // an inverse transform folded in), and the coset factor.  The factor s^i of a forward coset transform, i = i1 C + i2,
@@ -931,10 +950,10 @@ int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out, cons
 }
 
 int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned long long* d_result,
-                    uint4* d_res, uint4* d_dots, uint64_t dots_stride, uint32_t map_log_c = 0, uint32_t map_log_r = 0) {
+                    uint4* d_res, uint4* d_dots, uint64_t dots_stride, uint32_t map_log_run = 0, uint32_t map_log_r = 0) {
     acx_ctx* c = r->ctx;
     if (r->n == 0) return ACX_OK;
-    const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset, map_log_c, map_log_r};
+    const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset, map_log_run, map_log_r};
     const SellSystem S = sell_system(r, d_w, out);
     const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
     launch_sell(c, sell_spec(r), grid, nullptr, S);

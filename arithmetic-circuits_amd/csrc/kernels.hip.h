@@ -247,9 +247,10 @@ struct ResidualOut {
     u64 dots_stride;
     u64 row_offset;
     // first_bad numbering.  map_log_r == 0: row + row_offset (a contiguous slab of a larger system).  Otherwise the rows are a
-    // block-cyclic shard in ROWS order (include/acx.h, acx_mgpu_*): local row j = [kl][k2] with 2^map_log_c values of k2 is
-    // global row (row_offset + kl) + k2 * 2^map_log_r.  Only evaluated on the (rare) violated-row path.
-    u32 map_log_c, map_log_r;
+    // block-cyclic shard in ascending order (acx_mgpu_*, mgpu.inc.h): runs of 2^map_log_run consecutive rows, one run out
+    // of every 2^map_log_r -- local row j is global row row_offset + (j mod run) + (j / run) * 2^map_log_r.  Only
+    // evaluated on the (rare) violated-row path.
+    u32 map_log_run, map_log_r;
 };
 
 // per-lane epilogue shared by the SELL and the CSR-rows kernels.  Violations are the rare case: a
@@ -274,7 +275,7 @@ __device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, cons
     if (bad) {
         my_first = (u64)row + out.row_offset;
         if (out.map_log_r != 0)
-            my_first = out.row_offset + (row >> out.map_log_c) + ((u64)(row & ((1u << out.map_log_c) - 1u)) << out.map_log_r);
+            my_first = out.row_offset + (row & ((1u << out.map_log_run) - 1u)) + ((u64)(row >> out.map_log_run) << out.map_log_r);
     }
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_down(my_first, off, 64);

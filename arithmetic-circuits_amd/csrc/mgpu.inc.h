@@ -9,8 +9,10 @@
 //                 contiguous slabs balanced by nnz -- the rows in flight on a GPU gather from one narrow
 //                 window of the witness, which is worth 1.5-2x on the residual kernel (profiles/r02_dist_budget.txt).  For
 //                 h(x): block-cyclic -- with N = 2^log_n = R * C, shard g owns the rows k = k1 + k2 R with k1 in block g of R/W,
-//                 stored in ROWS order [kl][k2], so its residual kernel's <A_i,w>, <B_i,w>, <C_i,w> ARE three evaluation
-//                 vectors in the layout the first inverse transform reads (rows >= n are empty rows).
+//                 held in ASCENDING order (runs of R/W consecutive rows: the gathers of the rows in flight stay inside a
+//                 window 8x narrower than in ROWS order [kl][k2], profiles/r02_dist_budget.txt), so its residual kernel
+//                 writes <A_i,w>, <B_i,w>, <C_i,w> as the transposed ROWS block [k2][kl], which the first inverse step reads
+//                 through its strides (ntt_dist_step_locked, rows_transposed).  Rows >= n are empty rows.
 //                 ACX_MGPU_VERIFY_ONLY at load time skips the second copy.
 //   witness       replicated: one host-to-device copy per GPU (each over its own PCIe link, one host thread each)
 //   verdict       ONE ncclAllReduce (sum of the violated-row counts); a second one (min) only for first_bad of a failing check
@@ -144,7 +146,7 @@ struct acx_mgpu_r1cs {
     struct Part {
         acx_r1cs* slab = nullptr;                   // rows [row0, row0 + slab->n): what verifyAssignment runs on
         uint64_t row0 = 0;
-        acx_r1cs* cyc = nullptr;                    // this shard's N/W block-cyclic rows in ROWS order: what h(x) runs on (null: verify only)
+        acx_r1cs* cyc = nullptr;                    // this shard's N/W block-cyclic rows in ascending order: what h(x) runs on (null: verify only)
         uint4* d_w = nullptr;                       // the replicated witness, m dev elements
         uint4* vec = nullptr;                       // h(x) pipeline: dots 3L | coef 3L | pw L | h L (allocated on first use)
         unsigned long long* ring = nullptr;         // kMgRing result slots {n_bad, first_bad} of the asynchronous form + their reduction
@@ -262,7 +264,8 @@ struct MgNtt {
     }
 
     // in[s]: L dev elements per shard (COLS for a forward, ROWS for an inverse transform)
-    int begin(int k, uint4* const* in, int inverse, const H256* shift) {
+    // rows_transposed: the input of an inverse transform is in ascending row order [k2][kl] (the residual kernel's dots)
+    int begin(int k, uint4* const* in, int inverse, const H256* shift, bool rows_transposed = false) {
         const uint32_t W = mg->W;
         for (uint32_t s = 0; s < W; ++s) {
             MgShard& S = mg->sh[s];
@@ -271,7 +274,7 @@ struct MgNtt {
             if (!mg->rccl)                                          // peers still pulling the previous contents of send
                 for (uint32_t t = 0; t < W; ++t)
                     if (mg->sh[t].slot[k].got_valid) HIP_TRY(hipStreamWaitEvent(S.ctx->stream, mg->sh[t].slot[k].got, 0));
-            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 0, shift, in[s], S.slot[k].send));
+            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 0, shift, in[s], S.slot[k].send, rows_transposed));
             HIP_TRY(hipEventRecord(S.slot[k].sent, S.ctx->stream));
         }
         return exchange(k);
@@ -351,7 +354,6 @@ int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_
     acx_mgpu* mg = mr->mg;
     const uint32_t W = mg->W;
     const uint64_t L = (1ull << mr->log_n) / W, rw = (1ull << mr->log_r) / W;
-    const uint32_t log_c = mr->log_n - mr->log_r;
     for (uint32_t s = 0; s < W; ++s) {
         MgShard& S = mg->sh[s];
         HIP_TRY(hipSetDevice(S.device));
@@ -359,8 +361,8 @@ int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_
         static const unsigned long long init[2] = {0ull, ~0ull};
         HIP_TRY(hipMemcpyAsync(S.d_res, init, 16, hipMemcpyHostToDevice, S.ctx->stream));      // the canonicity flag stays
         const auto& P = mr->part[s];
-        if (with_dots)          // the block-cyclic copy: dots in ROWS layout, first_bad through the cyclic row map
-            ACX_TRY(launch_residual(P.cyc, P.d_w, (uint64_t)s * rw, S.d_res, nullptr, P.vec, L, log_c, mr->log_r));
+        if (with_dots)          // the block-cyclic copy: dots in ascending row order (= ROWS transposed), first_bad through the run map
+            ACX_TRY(launch_residual(P.cyc, P.d_w, (uint64_t)s * rw, S.d_res, nullptr, P.vec, L, mr->log_r - mg_log2(W), mr->log_r));
         else
             ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, S.d_res, nullptr, nullptr, 0));
     }
@@ -496,24 +498,27 @@ int mg_check_canonical(acx_mgpu* mg) {
     return ACX_OK;
 }
 
-// rows of one shard, in ROWS order, gathered from the caller's CSR (rows >= n: empty)
+// the block-cyclic rows of one shard in ASCENDING order (local row j = [k2][kl]: runs of R/W consecutive rows, one run out of
+// every R), gathered from the caller's CSR (rows >= n: empty)
 struct ShardRows {
     std::vector<uint32_t> rowptr, col;
     std::vector<acx_fr> val;
 };
 void mg_gather_rows(const acx_csr& M, uint64_t n, uint32_t log_n, uint32_t log_r, uint32_t W, uint32_t g, ShardRows& out) {
     const uint64_t R = 1ull << log_r, C = 1ull << (log_n - log_r), rw = R / W, L = rw * C;
+    const uint32_t log_rw = log_r - mg_log2(W);
+    auto global_row = [&](uint64_t j) { return (uint64_t)g * rw + (j & (rw - 1)) + ((j >> log_rw) << log_r); };     // ascending
     out.rowptr.assign(L + 1, 0);
     uint64_t nnz = 0;
     for (uint64_t j = 0; j < L; ++j) {
-        const uint64_t row = (uint64_t)g * rw + (j >> (log_n - log_r)) + ((j & (C - 1)) << log_r);
+        const uint64_t row = global_row(j);
         if (row < n) nnz += M.rowptr[row + 1] - M.rowptr[row];
         out.rowptr[j + 1] = (uint32_t)nnz;
     }
     out.col.resize(nnz);
     out.val.resize(nnz);
     for (uint64_t j = 0; j < L; ++j) {
-        const uint64_t row = (uint64_t)g * rw + (j >> (log_n - log_r)) + ((j & (C - 1)) << log_r);
+        const uint64_t row = global_row(j);
         if (row >= n) continue;
         const uint32_t e0 = M.rowptr[row], len = M.rowptr[row + 1] - e0;
         if (len == 0) continue;
@@ -653,7 +658,7 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
     // Software pipeline over the three vectors (qap_h_dev_locked's sequence, sharded): vector k's exchange runs on the
     // exchange streams under vector k+1's local step, and a vector's coset transform starts as soon as its inverse one is
     // complete -- of the six all-to-alls only the last has no local work to hide behind.
-    for (int k = 0; k < 3; ++k) ACX_TRY(nt.begin(k, ptrs((uint64_t)k * L).data(), 1, nullptr));
+    for (int k = 0; k < 3; ++k) ACX_TRY(nt.begin(k, ptrs((uint64_t)k * L).data(), 1, nullptr, true));     // dots: ascending row order
     for (int k = 0; k < 3; ++k) {
         ACX_TRY(nt.finish(k, ptrs((3 + (uint64_t)k) * L).data(), 1, nullptr));
         if (k < 2) ACX_TRY(nt.begin(k, ptrs((3 + (uint64_t)k) * L).data(), 0, &g));
