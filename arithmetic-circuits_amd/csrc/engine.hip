@@ -2165,9 +2165,11 @@ int acx_qap_sub_o_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_fr* 
     return ACX_OK;
 }
 
-int acx_ntt_dist_step_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
-                          const acx_fr* shift, const void* d_in, void* d_out) {
+int acx_ntt_dist_step_ex_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
+                             uint32_t flags, const acx_fr* shift, const void* d_in, void* d_out) {
     if (!c || !d_in || !d_out || (step != 0 && step != 1)) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    if (flags & ~(uint32_t)ACX_DIST_ROWS_T) return fail(ACX_ERR_INVALID_ARG, "unknown flag");
+    if ((flags & ACX_DIST_ROWS_T) && !(inverse && step == 0)) return fail(ACX_ERR_INVALID_ARG, "ACX_DIST_ROWS_T applies to inverse step 0");
     CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     H256 sh;
@@ -2176,7 +2178,12 @@ int acx_ntt_dist_step_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t w
         if (sh.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift must be nonzero");
     }
     return ntt_dist_step_locked(c, log_n, log_r, world, rank, inverse, step, shift ? &sh : nullptr, (const uint4*)d_in,
-                                (uint4*)d_out);
+                                (uint4*)d_out, (flags & ACX_DIST_ROWS_T) != 0);
+}
+
+int acx_ntt_dist_step_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
+                          const acx_fr* shift, const void* d_in, void* d_out) {
+    return acx_ntt_dist_step_ex_dev(c, log_n, log_r, world, rank, inverse, step, 0, shift, d_in, d_out);
 }
 
 // ---------------------------------------------------------------------------------- naive-roots path

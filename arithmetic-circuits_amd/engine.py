@@ -114,10 +114,11 @@ class Context:
         check(self.lib.acx_qap_sub_o_dev(self._h, log_n, count, _ptr(sh), d_h, d_o))
 
     def ntt_dist_step_dev(self, d_in: int, d_out: int, log_n: int, log_r: int, world: int, rank: int, inverse: bool, step: int,
-                          shift: Optional[int] = None) -> None:
-        """One local step of the distributed four-step NTT (include/acx.h: COLS / ROWS / XCHG layouts)."""
+                          shift: Optional[int] = None, rows_t: bool = False) -> None:
+        """One local step of the distributed four-step NTT (include/acx.h: COLS / ROWS / XCHG layouts); rows_t: the input of
+        an inverse step 0 is the transposed ROWS block (rows in ascending order), ACX_DIST_ROWS_T."""
         sh = ints_to_fr([shift]) if shift is not None else None
-        check(self.lib.acx_ntt_dist_step_dev(self._h, log_n, log_r, world, rank, int(inverse), step, _ptr(sh), d_in, d_out))
+        check(self.lib.acx_ntt_dist_step_ex_dev(self._h, log_n, log_r, world, rank, int(inverse), step, 1 if rows_t else 0, _ptr(sh), d_in, d_out))
 
 
 class R1CS:

@@ -17,10 +17,15 @@ below follows from the maths of the path:
     <A_i,w>, <B_i,w>, <C_i,w> straight into the layout the first inverse transform reads; six
     distributed transforms = six all-to-alls, nothing else moves.
 
-The collectives live here, above the C ABI; libacx only ever sees one GPU (a C host does the same
-with rcclCommInitRank / ncclAllToAll: INTEGRATION.md).  `LocalOps` is the seam: the product uses
-`HipOps` (HIP kernels through libacx); the CPU test-suite injects an oracle-backed implementation
-to exercise the distributed logic with the gloo backend."""
+This is the one-process-per-GPU launcher (what `torch.distributed.run` starts for bench.py): the collectives live here,
+above the C ABI, and libacx sees one GPU per process (a C host does the same with rcclCommInitRank / ncclAllToAll:
+INTEGRATION.md section 5).  The single-process alternative -- a device list, the sharding and the collectives INSIDE libacx -- is
+`acx_mgpu_*` (engine.MultiGpu).
+
+Three seams keep the sharding logic testable without several GPUs, each with exactly one product implementation here:
+`LocalRows` (a rank's rows: `HipLocalRows` = a device-resident acx_r1cs), `LocalOps` (a rank's transform steps: `HipOps`) and
+`Collectives` (all-reduce / all-to-all on `torch.distributed`, backend nccl = RCCL).  The CPU test-suite (tests/dist_worker.py)
+supplies oracle-backed rows and steps over gloo; the one-GPU tests supply a host-staged exchange (tests/helpers_dist.py)."""
 from __future__ import annotations
 
 from typing import Callable, List, Optional, Sequence, Tuple
@@ -38,6 +43,26 @@ def _world(group=None) -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)
     return 1, 0
+
+
+# ------------------------------------------------------------------------------------ collectives
+class Collectives:
+    """The two collectives of the path on a process group: torch.distributed, i.e. RCCL over xGMI with the nccl backend.
+    all_to_all returns a Work handle when the exchange is still in flight (RCCL runs it on its own stream), else None."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world, self.rank = _world(group)
+
+    def all_reduce(self, t: torch.Tensor, op) -> None:
+        dist.all_reduce(t, op=op, group=self.group)
+
+    def all_to_all(self, recv: torch.Tensor, send: torch.Tensor):
+        return dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+
+    def overlaps(self, like: torch.Tensor) -> bool:
+        """True when all_to_all returns with the exchange still in flight on another stream."""
+        return bool(like.is_cuda)
 
 
 # ------------------------------------------------------------------------------------ row ownership
@@ -81,74 +106,56 @@ def gather_rows(mat, rows: np.ndarray):
     return new_rp.astype(np.uint32), np.ascontiguousarray(col[src]), np.ascontiguousarray(val[src])
 
 
-def cyclic_rows(log_n: int, log_r: int, world: int, rank: int) -> np.ndarray:
-    """Global row numbers owned by `rank` under the block-cyclic ownership of SURVEY.md 8(e), in local
-    ROWS-layout order [kl][k2]: row = (rank*R/W + kl) + k2*R.  N/W entries (rows >= n are padding)."""
+def cyclic_rows(log_n: int, log_r: int, world: int, rank: int, ascending: bool = False) -> np.ndarray:
+    """Global row numbers owned by `rank` under the block-cyclic ownership of SURVEY.md 8(e): row = (rank*R/W + kl) + k2*R.
+    N/W entries (rows >= n are padding).  Default: local ROWS-layout order [kl][k2] (what a forward transform produces);
+    ascending: [k2][kl], the rows in increasing order -- the order a rank LOADS its rows in, because the gathers of the
+    rows in flight then stay inside a window 8x narrower; the dot products come out as the transposed ROWS block, which the
+    first inverse step reads through its strides (ACX_DIST_ROWS_T)."""
     R, C = 1 << log_r, 1 << (log_n - log_r)
     rw = R // world
     kl = np.arange(rw, dtype=np.int64).reshape(-1, 1)
     k2 = np.arange(C, dtype=np.int64).reshape(1, -1)
-    return (rank * rw + kl + k2 * R).reshape(-1)
+    rows = rank * rw + kl + k2 * R
+    return (rows.T if ascending else rows).reshape(-1)
 
 
 RowSource = Callable[[np.ndarray], Tuple[tuple, tuple, tuple]]
 
 
-class ShardedR1CS:
-    """A constraint system whose rows are sharded over the ranks of a process group.
+class LocalRows:
+    """A rank's rows of a sharded system: the seam between the sharding logic and the per-rank kernels.
+    `rows` = the rank's global row numbers in local order."""
+    rows: np.ndarray
+    m: int
 
-    Ownership: `rows` = this rank's global row numbers in local order (`from_slabs`: a contiguous
-    nnz-balanced slab; `from_cyclic`: the block-cyclic ownership the distributed h(x) pipeline needs).
-    Only those rows are marshalled and uploaded on this rank."""
+    def prepare(self, witness: np.ndarray):
+        """the (replicated) witness in whatever form verify() takes"""
+        raise NotImplementedError
 
-    def __init__(self, rows: np.ndarray, local_mats, n: int, m: int, group=None, ctx: Optional[Context] = None,
-                 local_verify=None, local_dots=None):
-        """local_verify(mats_local, m, witness, rows) -> (n_bad, smallest violated GLOBAL row) and local_dots(mats_local, m, witness) ->
-        (3*rows, 4) int64 tensor replace the HIP path in CPU tests; the product path requires `ctx` (a GPU
-        context) and has no fallback."""
-        self.group = group
-        self.world, self.rank = _world(group)
+    def verify(self, w, want_first: bool = False, dots: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Local check on a prepared witness: (verdict = [violated rows, non-canonical flag], first = [smallest violated GLOBAL
+        row or 2^62]) as int64 tensors, not yet reduced over the ranks; dots (3 * len(rows) elements) receives <A_i,w>, <B_i,w>,
+        <C_i,w> of the local rows in local order when given."""
+        raise NotImplementedError
+
+
+class HipLocalRows(LocalRows):
+    """The product implementation: the rank's rows as a device-resident acx_r1cs, checked by the HIP residual kernel."""
+
+    def __init__(self, ctx: Context, rows: np.ndarray, m: int, local_mats):
+        if ctx is None:
+            raise RuntimeError("a sharded system needs a GPU Context (libacx has no CPU fallback)")
+        self.ctx, self.m = ctx, m
         self.rows = np.asarray(rows, dtype=np.int64)
-        self.local_mats = local_mats
-        self.n, self.m = n, m
-        self._local_verify = local_verify
-        self._local_dots = local_dots
-        self.ctx = ctx
-        self.r1cs = None
-        if local_verify is None:
-            if ctx is None:
-                raise RuntimeError("ShardedR1CS needs a GPU Context (libacx has no CPU fallback)")
-            self.r1cs = R1CS.load(ctx, self.rows.shape[0], m, *local_mats)
-            dev = f"cuda:{ctx.device}"
-            self._res = torch.zeros(2, dtype=torch.int64, device=dev)
-            self._flag = torch.zeros(2, dtype=torch.int32, device=dev)       # [0] = non-canonical witness
-            self._stream = torch.cuda.ExternalStream(ctx.stream)
+        self.r1cs = R1CS.load(ctx, self.rows.shape[0], m, *local_mats)
+        dev = f"cuda:{ctx.device}"
+        self._res = torch.zeros(2, dtype=torch.int64, device=dev)
+        self._flag = torch.zeros(2, dtype=torch.int32, device=dev)       # [0] = non-canonical witness
+        self._stream = torch.cuda.ExternalStream(ctx.stream)
+        self._monotone = self.rows.shape[0] < 2 or bool(np.all(np.diff(self.rows) > 0))
 
-    # -- constructors ---------------------------------------------------------------------------
-    @classmethod
-    def from_slabs(cls, mats, m: int, **kw) -> "ShardedR1CS":
-        """Contiguous slabs balanced by nnz.  `mats` is the full host CSR triple (cheap for the sizes where a
-        single host can hold it; large jobs use `from_source`)."""
-        world, rank = _world(kw.get("group"))
-        n = len(mats[0][0]) - 1
-        bounds = shard_bounds([mt[0] for mt in mats], world)
-        lo, hi = bounds[rank], bounds[rank + 1]
-        self = cls(np.arange(lo, hi, dtype=np.int64), [slice_rows(mt, lo, hi) for mt in mats], n, m, **kw)
-        self.bounds = bounds
-        return self
-
-    @classmethod
-    def from_source(cls, source: RowSource, rows: np.ndarray, n: int, m: int, **kw) -> "ShardedR1CS":
-        """Rank-local construction: `source(rows)` returns the CSR triples of exactly these global rows."""
-        return cls(rows, list(source(rows)), n, m, **kw)
-
-    @classmethod
-    def from_cyclic(cls, source: RowSource, n: int, m: int, log_n: int, log_r: int, **kw) -> "ShardedR1CS":
-        world, rank = _world(kw.get("group"))
-        return cls.from_source(source, cyclic_rows(log_n, log_r, world, rank), n, m, **kw)
-
-    # -- verifyAssignment -------------------------------------------------------------------------
-    def to_device_witness(self, witness: np.ndarray) -> torch.Tensor:
+    def prepare(self, witness: np.ndarray) -> torch.Tensor:
         """Upload + convert the (replicated) witness; canonicity is checked on the device like the single-GPU path
         does (acx_r1cs_verify): the flag travels with the verdict's all-reduce."""
         ctx = self.ctx
@@ -158,39 +165,25 @@ class ShardedR1CS:
         ctx.dev_from_canonical(self.m, w.data_ptr(), w.data_ptr(), self._flag.data_ptr())
         return w
 
-    def verify(self, witness: np.ndarray, want_first: bool = False) -> Tuple[bool, int, int]:
-        """verifyAssignment over all shards: (ok, n_bad, first_bad) identical on every rank.  ONE collective;
-        first_bad (smallest violated global row) costs a second one and is U64_MAX unless want_first."""
-        if self._local_verify is not None:
-            n_bad, first_global = self._local_verify(self.local_mats, self.m, witness, self.rows)
-            verdict = torch.tensor([n_bad, 0], dtype=torch.int64)
-            first = torch.tensor([first_global if n_bad else (1 << 62)], dtype=torch.int64)
-        else:
-            w = self.to_device_witness(witness)
-            verdict, first = self.verify_dev(w, want_first)
-        return self._reduce(verdict, first, want_first)
-
-    def verify_dev(self, w: torch.Tensor, want_first: bool = False, dots: Optional[torch.Tensor] = None):
-        """Local launch on a device-resident witness; returns the (not yet reduced) verdict tensors."""
+    def verify(self, w: torch.Tensor, want_first: bool = False, dots: Optional[torch.Tensor] = None):
         none = 1 << 62
-        monotone = self.rows.shape[0] < 2 or bool(np.all(np.diff(self.rows) > 0))
         res_vec = None
         with torch.cuda.stream(self._stream):
             self._res.copy_(torch.tensor([0, -1], dtype=torch.int64), non_blocking=False)
-            if want_first and not monotone:
+            if want_first and not self._monotone:
                 res_vec = torch.empty((self.rows.shape[0], 4), dtype=torch.int64, device=self._res.device)
             self.r1cs.verify_dev(w.data_ptr(), self._res.data_ptr(), d_dots=dots.data_ptr() if dots is not None else 0,
                                  d_residuals=res_vec.data_ptr() if res_vec is not None else 0)
             verdict = torch.stack([self._res[0], self._flag[0].to(torch.int64)])
             first = torch.full((1,), none, dtype=torch.int64, device=self._res.device)
-            if want_first and monotone:
+            if want_first and self._monotone:
                 # the kernel's first_bad is the smallest LOCAL row (unsigned, UINT64_MAX = none); local order is
                 # increasing in the global row number here, so it maps straight to the global row
                 pos = self._res[1:2]
                 rows = torch.from_numpy(self.rows).to(pos.device)
                 first = torch.where(pos < 0, first, rows[pos.clamp(min=0, max=rows.shape[0] - 1)])
             elif want_first:
-                # block-cyclic ownership: local order is not global order; take the residual vector (on request only)
+                # local order is not global order (ROWS-order ownership): take the residual vector (on request only)
                 self.ctx.dev_to_canonical(res_vec.shape[0], res_vec.data_ptr(), res_vec.data_ptr())
                 bad = (res_vec != 0).any(dim=1)
                 rows = torch.from_numpy(self.rows).to(bad.device)
@@ -198,21 +191,86 @@ class ShardedR1CS:
         self._stream.synchronize()
         return verdict, first
 
+
+LocalFactory = Callable[[np.ndarray, int, list], LocalRows]
+
+
+class ShardedR1CS:
+    """A constraint system whose rows are sharded over the ranks of a process group.
+
+    Ownership: `rows` = this rank's global row numbers in local order (`from_slabs`: a contiguous nnz-balanced slab;
+    `from_cyclic`: the block-cyclic ownership the distributed h(x) pipeline needs).  Only those rows are marshalled and
+    uploaded on this rank.  `ctx` selects the product's HipLocalRows; `local_factory(rows, m, local_mats)` supplies
+    another LocalRows, `collectives` another Collectives."""
+
+    def __init__(self, local: LocalRows, n: int, m: int, collectives: Optional[Collectives] = None):
+        self.local = local
+        self.coll = collectives if collectives is not None else Collectives()
+        self.world, self.rank = self.coll.world, self.coll.rank
+        self.n, self.m = n, m
+        self.rows_t = False
+
+    @property
+    def rows(self) -> np.ndarray:
+        return self.local.rows
+
+    @property
+    def r1cs(self):
+        return getattr(self.local, "r1cs", None)
+
+    # -- constructors ---------------------------------------------------------------------------
+    @classmethod
+    def from_source(cls, source: RowSource, rows: np.ndarray, n: int, m: int, ctx: Optional[Context] = None,
+                    local_factory: Optional[LocalFactory] = None, collectives: Optional[Collectives] = None) -> "ShardedR1CS":
+        """Rank-local construction: `source(rows)` returns the CSR triples of exactly these global rows."""
+        mats = list(source(rows))
+        rows = np.asarray(rows, dtype=np.int64)
+        local = local_factory(rows, m, mats) if local_factory is not None else HipLocalRows(ctx, rows, m, mats)
+        return cls(local, n, m, collectives)
+
+    @classmethod
+    def from_slabs(cls, mats, m: int, collectives: Optional[Collectives] = None, **kw) -> "ShardedR1CS":
+        """Contiguous slabs balanced by nnz.  `mats` is the full host CSR triple (cheap for the sizes where a
+        single host can hold it; large jobs use `from_source`)."""
+        coll = collectives if collectives is not None else Collectives()
+        n = len(mats[0][0]) - 1
+        bounds = shard_bounds([mt[0] for mt in mats], coll.world)
+        lo, hi = bounds[coll.rank], bounds[coll.rank + 1]
+        self = cls.from_source(lambda rows: [slice_rows(mt, lo, hi) for mt in mats], np.arange(lo, hi, dtype=np.int64), n, m,
+                               collectives=coll, **kw)
+        self.bounds = bounds
+        return self
+
+    @classmethod
+    def from_cyclic(cls, source: RowSource, n: int, m: int, log_n: int, log_r: int, ascending: bool = True,
+                    collectives: Optional[Collectives] = None, **kw) -> "ShardedR1CS":
+        """Block-cyclic ownership for the distributed h(x); `ascending` (default) loads the rank's rows in increasing order
+        and marks the dot products as the transposed ROWS block (DistributedQapH passes that on to the first inverse steps)."""
+        coll = collectives if collectives is not None else Collectives()
+        self = cls.from_source(source, cyclic_rows(log_n, log_r, coll.world, coll.rank, ascending), n, m, collectives=coll, **kw)
+        self.rows_t = ascending
+        return self
+
+    # -- verifyAssignment -------------------------------------------------------------------------
+    def verify(self, witness: np.ndarray, want_first: bool = False) -> Tuple[bool, int, int]:
+        """verifyAssignment over all shards: (ok, n_bad, first_bad) identical on every rank.  ONE collective;
+        first_bad (smallest violated global row) costs a second one and is U64_MAX unless want_first."""
+        verdict, first = self.local.verify(self.local.prepare(witness), want_first)
+        return self._reduce(verdict, first, want_first)
+
+    def verify_dev(self, w, want_first: bool = False, dots: Optional[torch.Tensor] = None):
+        """Local launch on a prepared (device-resident) witness; returns the (not yet reduced) verdict tensors."""
+        return self.local.verify(w, want_first, dots)
+
     def dots(self, w, out: torch.Tensor):
         """<A_i,w>, <B_i,w>, <C_i,w> of the local rows into out (3 * rows elements), plus the local verdict."""
-        if self._local_dots is not None:
-            out.copy_(self._local_dots(self.local_mats, self.m, w))
-            n_bad, _ = self._local_verify(self.local_mats, self.m, w, self.rows)
-            return torch.tensor([n_bad, 0], dtype=torch.int64), torch.tensor([1 << 62], dtype=torch.int64)
-        return self.verify_dev(w, dots=out)
+        return self.local.verify(w, False, out)
 
     def _reduce(self, verdict: torch.Tensor, first: torch.Tensor, want_first: bool) -> Tuple[bool, int, int]:
-        if self.world > 1 and verdict.is_cuda and dist.get_backend(self.group) == "gloo":
-            verdict, first = verdict.cpu(), first.cpu()          # several ranks on one GPU over gloo (tests)
         if self.world > 1:
-            dist.all_reduce(verdict, op=dist.ReduceOp.SUM, group=self.group)          # THE verdict collective
+            self.coll.all_reduce(verdict, dist.ReduceOp.SUM)          # THE verdict collective
             if want_first:
-                dist.all_reduce(first, op=dist.ReduceOp.MIN, group=self.group)
+                self.coll.all_reduce(first, dist.ReduceOp.MIN)
         n_bad, noncanon = int(verdict[0]), int(verdict[1])
         if noncanon:
             from ._lib import AcxError, STATUS
@@ -227,7 +285,8 @@ class LocalOps:
     elements, shape (count, 4), in whatever element format the implementation uses."""
 
     def dist_step(self, src: torch.Tensor, dst: torch.Tensor, log_n: int, log_r: int, world: int, rank: int,
-                  inverse: bool, step: int, shift: Optional[int]) -> None:
+                  inverse: bool, step: int, shift: Optional[int], rows_t: bool = False) -> None:
+        """rows_t (inverse step 0 only): src is the transposed ROWS block [k2][kl] (include/acx.h, ACX_DIST_ROWS_T)."""
         raise NotImplementedError
 
     def pointwise_h(self, a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], out: torch.Tensor, log_n: int, shift: int) -> None:
@@ -256,9 +315,9 @@ class HipOps(LocalOps):
         if cur.cuda_stream != self._ext.cuda_stream:
             cur.wait_stream(self._ext)
 
-    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift):
+    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift, rows_t=False):
         assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()
-        self._fenced(lambda: self.ctx.ntt_dist_step_dev(src.data_ptr(), dst.data_ptr(), log_n, log_r, world, rank, inverse, step, shift))
+        self._fenced(lambda: self.ctx.ntt_dist_step_dev(src.data_ptr(), dst.data_ptr(), log_n, log_r, world, rank, inverse, step, shift, rows_t))
 
     def pointwise_h(self, a, b, c, out, log_n, shift):
         self._fenced(lambda: self.ctx.qap_pointwise_dev(a.data_ptr(), b.data_ptr(), c.data_ptr() if c is not None else None,
@@ -280,10 +339,12 @@ class DistributedNTT:
     every link busy); a pipeline of transforms (the 6 NTTs of h(x)) alternates the two layouts, so nothing is
     ever re-ordered in between."""
 
-    def __init__(self, log_n: int, ops: LocalOps, group=None, log_r: Optional[int] = None, force_collective: bool = False):
-        self.group = group
-        self.world, self.rank = _world(group)
-        self.force_collective = force_collective        # issue the collective even with one rank (RCCL smoke test on one GPU)
+    def __init__(self, log_n: int, ops: LocalOps, group=None, log_r: Optional[int] = None, force_collective: bool = False,
+                 collectives: Optional[Collectives] = None):
+        self.coll = collectives if collectives is not None else Collectives(group)
+        self.group = self.coll.group
+        self.world, self.rank = self.coll.world, self.coll.rank
+        self.force_collective = force_collective        # issue the collective even with one rank: a one-rank RCCL communicator still runs the exchange
         self.log_n = log_n
         self.log_r = log_r if log_r is not None else log_n // 2
         self.log_c = log_n - self.log_r
@@ -321,7 +382,7 @@ class DistributedNTT:
     def overlapped(self, like: torch.Tensor) -> bool:
         """True when begin() returns with the exchange still in flight: RCCL runs the collective on its own stream, so
         the caller's next local step (another transform of the pipeline) overlaps it."""
-        return bool(like.is_cuda and self._exchanges() and dist.get_backend(self.group) == "nccl")
+        return bool(self._exchanges() and self.coll.overlaps(like))
 
     def stream_context(self):
         """The HIP stream every step of a pipeline is issued on (libacx's own, for HipOps): collectives are ordered
@@ -344,32 +405,19 @@ class DistributedNTT:
             outer.wait_stream(ext)
         return fenced()
 
-    def begin(self, x: torch.Tensor, inverse: bool, shift: Optional[int] = None, slot: int = 0):
+    def begin(self, x: torch.Tensor, inverse: bool, shift: Optional[int] = None, slot: int = 0, rows_t: bool = False):
         """First local step of one transform and the START of its all-to-all (src/QAP.hs:512-525's transform, sharded).
         Returns a token for finish().  Transforms in flight at the same time need different slots (buffer pairs)."""
         assert x.shape == (self.local, 4) and x.is_contiguous()
         send, recv = self._buffers(x, slot)
         a = (self.log_n, self.log_r, self.world, self.rank, inverse)
-        self.ops.dist_step(x, send, *a, 0, shift)
+        self.ops.dist_step(x, send, *a, 0, shift, rows_t)
         work, got = None, send
         if self._exchanges():
-            if self.overlapped(x):
-                # enqueued behind the local step on the current stream; returns at once, the copy engine / xGMI links
-                # work while the SIMDs run the next transform's local step
-                work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
-                got = recv
-            elif x.is_cuda and dist.get_backend(self.group) == "gloo":
-                # gloo has no CUDA all-to-all: stage through the host (test configurations with several ranks on one
-                # GPU; a real multi-GPU job uses the nccl = RCCL backend and never comes here)
-                torch.cuda.synchronize()
-                sh = send.cpu()
-                rh = torch.empty_like(sh)
-                dist.all_to_all_single(rh, sh, group=self.group)
-                recv.copy_(rh)
-                got = recv
-            else:
-                dist.all_to_all_single(recv, send, group=self.group)
-                got = recv
+            # enqueued behind the local step on the current stream; with RCCL it returns at once and the xGMI links work while
+            # the SIMDs run the next transform's local step
+            work = self.coll.all_to_all(recv, send)
+            got = recv
         return (work, got, a, shift)
 
     def finish(self, token, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -382,15 +430,16 @@ class DistributedNTT:
         self.ops.dist_step(got, out, *a, 1, shift)
         return out
 
-    def _run(self, x: torch.Tensor, out: Optional[torch.Tensor], inverse: bool, shift: Optional[int]) -> torch.Tensor:
+    def _run(self, x: torch.Tensor, out: Optional[torch.Tensor], inverse: bool, shift: Optional[int], rows_t: bool = False) -> torch.Tensor:
         with self.stream_context():
-            return self.finish(self.begin(x, inverse, shift), out)
+            return self.finish(self.begin(x, inverse, shift, rows_t=rows_t), out)
 
     def forward(self, cols: torch.Tensor, out: Optional[torch.Tensor] = None, shift: Optional[int] = None) -> torch.Tensor:
         return self._run(cols, out, False, shift)
 
-    def inverse(self, rows: torch.Tensor, out: Optional[torch.Tensor] = None, shift: Optional[int] = None) -> torch.Tensor:
-        return self._run(rows, out, True, shift)
+    def inverse(self, rows: torch.Tensor, out: Optional[torch.Tensor] = None, shift: Optional[int] = None, rows_t: bool = False) -> torch.Tensor:
+        """rows_t: `rows` is the transposed ROWS block [k2][kl] (the dots of rows loaded in ascending order)."""
+        return self._run(rows, out, True, shift, rows_t)
 
 
 class DistributedQapH:
@@ -423,7 +472,7 @@ class DistributedQapH:
         # the six all-to-alls only the last one has no local work to hide behind.  Without an overlapping backend
         # (one rank, gloo) begin() completes the exchange itself and this is the plain sequence.
         with nt.stream_context():
-            inv = [nt.begin(part(dots, k), True, None, slot=k) for k in range(3)]
+            inv = [nt.begin(part(dots, k), True, None, slot=k, rows_t=self.sharded.rows_t) for k in range(3)]
             fwd = []
             for k in range(3):
                 nt.finish(inv[k], out=part(tmp, k))

@@ -227,6 +227,10 @@ def bench_distributed(ctx, a, world, rank, dist):
     from oracle.c_oracle import COracle
     orc = COracle(a.field)
     ops = par.HipOps(ctx)
+    coll = None                                      # the product's collectives: torch.distributed over RCCL
+    if a.backend == "gloo":                          # test mode (several ranks sharing one GPU): host-staged exchange
+        from tests.helpers_dist import HostStagedCollectives
+        coll = HostStagedCollectives()
     dev = torch.device("cuda", torch.cuda.current_device())
 
     def tmax(x):
@@ -250,13 +254,13 @@ def bench_distributed(ctx, a, world, rank, dist):
     # --- parity of the distributed transform against the oracle at 2^16 (same kernels, same exchange)
     ln = 16
     force = world == 1 and a.backend == "nccl"      # one rank: still issue the RCCL all-to-all (its stream ordering is what is tested)
-    d16 = par.DistributedNTT(ln, ops, log_r=8, force_collective=force)
+    d16 = par.DistributedNTT(ln, ops, log_r=8, force_collective=force, collectives=coll)
     x16 = synth.random_fr(1 << ln, 31, 1, a.field)
     got = _from_dev(ctx, d16.forward(to_dev(ctx, x16[d16.cols_indices()])), d16.local)
     parity = bool(np.array_equal(got, orc.ntt(x16, ln, nthreads=os.cpu_count() or 1)[d16.rows_indices()]))
     # --- 2^24 transform
     ln, lr = a.dist_logn, a.dist_logn // 2
-    d = par.DistributedNTT(ln, ops, log_r=lr, force_collective=force)
+    d = par.DistributedNTT(ln, ops, log_r=lr, force_collective=force, collectives=coll)
     x = to_dev(ctx, synth.random_fr(d.local, 32 + rank, 1, a.field))
     y = torch.empty_like(x)
     z = torch.empty_like(x)
@@ -283,7 +287,7 @@ def bench_distributed(ctx, a, world, rank, dist):
     # --- h(x) on the 2^24-constraint block system
     blocks = n >> 16
     bs = synth.BlockSystem(synth.mulgraph(1 << 16, seed=0xAC4, field=a.field), blocks)
-    sh = par.ShardedR1CS.from_cyclic(bs.rows_of, bs.n, bs.m, ln, lr, ctx=ctx)
+    sh = par.ShardedR1CS.from_cyclic(bs.rows_of, bs.n, bs.m, ln, lr, ctx=ctx, collectives=coll)
     qh = par.DistributedQapH(sh, d, orc.generator)
     w = bs.witness()
     dw = to_dev(ctx, w)

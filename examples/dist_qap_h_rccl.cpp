@@ -2,8 +2,9 @@
 // over several GPUs from a C/C++ host, no Python: one process per GPU, the local work through include/acx.h, the
 // exchanges through RCCL on libacx's own stream.  BASELINE.json configs[3] in small: the recipe of INTEGRATION.md section 4.
 //
-//   rows          every rank loads ONLY its rows, block-cyclic: local row [kl][k2] = global row (rank*R/W + kl) + k2*R, so the
-//                 residual kernel's <A_i,w>, <B_i,w>, <C_i,w> ARE three evaluation vectors in the ROWS layout
+//   rows          every rank loads ONLY its rows, block-cyclic and in ascending order: local row [k2][kl] = global row
+//                 (rank*R/W + kl) + k2*R, so the residual kernel's <A_i,w>, <B_i,w>, <C_i,w> ARE three evaluation vectors in the
+//                 transposed ROWS layout, which the first inverse steps read through their strides (ACX_DIST_ROWS_T)
 //   3 inverse     acx_ntt_dist_step_dev(step 0) -> ncclAllToAll -> (step 1): coefficients of L, R, O in COLS ownership
 //   2 coset       L and R only: O(x) enters the quotient in coefficient form (include/acx.h, acx_qap_sub_o_dev)
 //   pointwise     acx_qap_pointwise_dev(.., d_c = NULL, ..)
@@ -94,9 +95,10 @@ int main() {
     for (uint64_t i = 0; i < N; ++i) wi[1 + K + i] = wi[a_of(i)] * (wi[b_of(i)] + 3);
     for (uint64_t k = 0; k < m; ++k) w[k] = fr_u64(wi[k]);
 
-    // ---- this rank's rows in ROWS order, and (for the check) the whole system in natural order
+    // ---- this rank's rows in ASCENDING order (local row [k2][kl]: runs of R/W consecutive rows -- the gathers of the rows in
+    // flight stay in a narrow window of the witness), and (for the check) the whole system in natural order
     std::vector<uint64_t> mine(L), all(N);
-    for (uint64_t kl = 0; kl < rw; ++kl) for (uint64_t k2 = 0; k2 < C; ++k2) mine[kl * C + k2] = (rank * rw + kl) + k2 * R;
+    for (uint64_t k2 = 0; k2 < C; ++k2) for (uint64_t kl = 0; kl < rw; ++kl) mine[k2 * rw + kl] = (rank * rw + kl) + k2 * R;
     for (uint64_t i = 0; i < N; ++i) all[i] = i;
     acx_r1cs *r_local = nullptr, *r_full = nullptr;
     ACXCHECK(load(ctx, rows_of(mine), L, m, &r_local));
@@ -115,8 +117,9 @@ int main() {
         NCCLCHECK(ncclAllToAll(s, r, L * 32 / world, ncclUint8, comm, stream));
         return 0;
     };
-    auto transform = [&](int inverse, const acx_fr* shift, void* in, void* out) -> int {
-        ACXCHECK(acx_ntt_dist_step_dev(ctx, log_n, log_r, world, rank, inverse, 0, shift, in, send));
+    // rows_t: `in` is the transposed ROWS block [k2][kl] -- what the residual kernel writes for rows loaded in ascending order
+    auto transform = [&](int inverse, const acx_fr* shift, void* in, void* out, uint32_t rows_t = 0) -> int {
+        ACXCHECK(acx_ntt_dist_step_ex_dev(ctx, log_n, log_r, world, rank, inverse, 0, rows_t, shift, in, send));
         if (exchange(send, recv)) return 1;
         ACXCHECK(acx_ntt_dist_step_dev(ctx, log_n, log_r, world, rank, inverse, 1, shift, recv, out));
         return 0;
@@ -130,8 +133,8 @@ int main() {
         ACXCHECK(acx_dev_from_canonical(ctx, m, d_w, d_w, nullptr));
         const uint64_t init[2] = {0, ~0ull};
         HIPCHECK(hipMemcpyAsync(d_res, init, 16, hipMemcpyHostToDevice, stream));
-        ACXCHECK(acx_r1cs_verify_dev(r_local, d_w, 0, d_res, nullptr, dots));               // dots: ROWS layout, three vectors
-        for (uint64_t k = 0; k < 3; ++k) if (transform(1, nullptr, at(dots, k), at(coef, k))) return 1;      // -> coefficients (COLS)
+        ACXCHECK(acx_r1cs_verify_dev(r_local, d_w, 0, d_res, nullptr, dots));               // dots: transposed ROWS layout, three vectors
+        for (uint64_t k = 0; k < 3; ++k) if (transform(1, nullptr, at(dots, k), at(coef, k), ACX_DIST_ROWS_T)) return 1;      // -> coefficients (COLS)
         for (uint64_t k = 0; k < 2; ++k) if (transform(0, &g, at(coef, k), at(dots, k))) return 1;           // L, R on the coset (ROWS)
         ACXCHECK(acx_qap_pointwise_dev(ctx, log_n, L, &g, at(dots, 0), at(dots, 1), nullptr, tmp));
         if (transform(1, &g, tmp, h)) return 1;                                                               // -> COLS

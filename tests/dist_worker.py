@@ -38,7 +38,7 @@ class OracleOps(par.LocalOps):
     def _ntt(self, vals, log_len, inverse):
         return limbs_to_ints(self.orc.ntt(ints_to_limbs(vals), log_len, inverse=inverse))
 
-    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift):
+    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift, rows_t=False):
         p = self.orc.p
         N, R = 1 << log_n, 1 << log_r
         C = N // R
@@ -47,6 +47,9 @@ class OracleOps(par.LocalOps):
         if inverse:
             w = pow(w, -1, p)
         a = _ints(src)
+        if rows_t:                               # [k2][kl] -> [kl][k2]: the contract of ACX_DIST_ROWS_T
+            assert inverse and step == 0
+            a = [a[k2 * rw + kl] for kl in range(rw) for k2 in range(C)]
         out = [0] * (N // world)
         if not inverse and step == 0:            # COLS -> XCHG
             for i2l in range(cw):
@@ -100,25 +103,34 @@ def main():
     mats, w = s.rows(), s.witness()
     n, m = s.circuit.n_rows, s.circuit.m
 
-    def local_verify(lm, m_, wit, rows):
-        res, nbad, _ = orc.r1cs_residuals(len(lm[0][0]) - 1, m_, *lm, wit)
-        badrows = rows[res.any(axis=1)]
-        return nbad, (int(badrows.min()) if nbad else 0)
+    class OracleRows(par.LocalRows):
+        """A rank's rows checked by the CPU oracle: the test double of parallel.HipLocalRows."""
 
-    def local_dots(lm, m_, wit):
-        wi = limbs_to_ints(wit)
-        vals = []
-        for rowptr, col, val in lm:
-            v = limbs_to_ints(val)
-            vals += [sum(v[e] * wi[int(col[e])] for e in range(int(rowptr[i]), int(rowptr[i + 1]))) % p
-                     for i in range(len(rowptr) - 1)]
-        return _tensor(vals)
+        def __init__(self, rows, m_, lm):
+            self.rows, self.m, self.lm = np.asarray(rows, dtype=np.int64), m_, lm
+
+        def prepare(self, witness):
+            return witness
+
+        def verify(self, wit, want_first=False, dots=None):
+            res, nbad, _ = orc.r1cs_residuals(len(self.lm[0][0]) - 1, self.m, *self.lm, wit)
+            badrows = self.rows[res.any(axis=1)]
+            if dots is not None:
+                wi = limbs_to_ints(wit)
+                vals = []
+                for rowptr, col, val in self.lm:
+                    v = limbs_to_ints(val)
+                    vals += [sum(v[e] * wi[int(col[e])] for e in range(int(rowptr[i]), int(rowptr[i + 1]))) % p
+                             for i in range(len(rowptr) - 1)]
+                dots.copy_(_tensor(vals))
+            return (torch.tensor([nbad, 0], dtype=torch.int64),
+                    torch.tensor([int(badrows.min()) if nbad else (1 << 62)], dtype=torch.int64))
 
     bad = w.copy()
     for k in (40, 900, 2000):
         bad[k, 0] ^= np.uint64(1)
     _, want_bad, want_first = orc.r1cs_residuals(n, m, *mats, bad, want_residuals=False)
-    sh = par.ShardedR1CS.from_slabs(mats, m, local_verify=local_verify)
+    sh = par.ShardedR1CS.from_slabs(mats, m, local_factory=OracleRows)
     assert sh.bounds[0] == 0 and sh.bounds[-1] == n and all(a <= b for a, b in zip(sh.bounds, sh.bounds[1:]))
     assert sh.verify(w) == (True, 0, par.U64_MAX)
     assert sh.verify(bad) == (False, want_bad, par.U64_MAX)                  # one collective: no first_bad
@@ -126,9 +138,10 @@ def main():
     # block-cyclic ownership, rows marshalled per rank from a row source (here: gathered from the host CSR)
     log_n, log_r = 11, 5
     source = lambda rows: tuple(par.gather_rows(mt, rows) for mt in mats)
-    shc = par.ShardedR1CS.from_cyclic(source, n, m, log_n, log_r, local_verify=local_verify, local_dots=local_dots)
-    own = par.cyclic_rows(log_n, log_r, world, rank)
-    assert np.array_equal(shc.rows, own) and len(own) == (1 << log_n) // world
+    shc = par.ShardedR1CS.from_cyclic(source, n, m, log_n, log_r, local_factory=OracleRows)
+    own = par.cyclic_rows(log_n, log_r, world, rank, ascending=True)          # from_cyclic's default: ascending row order
+    assert np.array_equal(shc.rows, own) and len(own) == (1 << log_n) // world and shc.rows_t
+    assert np.all(np.diff(own) > 0) and sorted(own.tolist()) == sorted(par.cyclic_rows(log_n, log_r, world, rank).tolist())
     allrows = [torch.zeros(len(own), dtype=torch.int64) for _ in range(world)]
     dist.all_gather(allrows, torch.from_numpy(own))
     assert sorted(torch.cat(allrows).tolist()) == list(range(1 << log_n))      # a partition of the padded domain

@@ -1,8 +1,8 @@
 """Worker for test_gpu_parity.py::test_sharded_layer_two_ranks_on_one_device: the multi-GPU host layer
 with the PRODUCT local kernels (libacx through HipOps / ShardedR1CS), two ranks sharing cuda:0 over gloo
 (RCCL needs one GPU per rank; the sharding logic and the stream fencing do not).  gloo has no CUDA
-all-to-all, so parallel.py stages the exchange through host memory under that backend; everything else is
-the code path of a multi-GPU run."""
+all-to-all, so the collectives are tests/helpers_dist.py's host-staged ones; everything else is the code path of a
+multi-GPU run."""
 import importlib
 import os
 import sys
@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle.c_oracle import COracle                  # noqa: E402
+from tests.helpers_dist import HostStagedCollectives  # noqa: E402
 
 acx = importlib.import_module("arithmetic-circuits_amd")
 par = importlib.import_module("arithmetic-circuits_amd.parallel")
@@ -48,7 +49,8 @@ def main():
     s = synth.mulgraph(1 << 14, n_in=64, window=512, seed=7)
     mats, w = s.rows(), s.witness()
     n, m = s.circuit.n_rows, s.circuit.m
-    sh = par.ShardedR1CS.from_slabs(mats, m, ctx=ctx)
+    coll = HostStagedCollectives()
+    sh = par.ShardedR1CS.from_slabs(mats, m, ctx=ctx, collectives=coll)
     assert sh.r1cs is not None and sh.rows.shape[0] < n
     assert sh.verify(w) == (True, 0, par.U64_MAX)
     bad = w.copy()
@@ -63,7 +65,7 @@ def main():
     for log_n, log_r in ((12, 6), (15, 7), (16, 8)):
         N = 1 << log_n
         x = synth.random_fr(N, 11, log_n)
-        d = par.DistributedNTT(log_n, ops, log_r=log_r)
+        d = par.DistributedNTT(log_n, ops, log_r=log_r, collectives=coll)
         mine = dev(ctx, x[d.cols_indices()])
         for shift in (None, orc.generator):
             want = orc.ntt(x, log_n, shift=shift, nthreads=4)
@@ -75,10 +77,10 @@ def main():
     # ---- the whole C4 pipeline: block-cyclic rows marshalled per rank, distributed h(x) == oracle
     log_n, log_r = 14, 7
     source = lambda rows: tuple(par.gather_rows(mt, rows) for mt in mats)
-    shc = par.ShardedR1CS.from_cyclic(source, n, m, log_n, log_r, ctx=ctx)
+    shc = par.ShardedR1CS.from_cyclic(source, n, m, log_n, log_r, ctx=ctx, collectives=coll)
     assert shc.rows.shape[0] == n // world
     assert shc.verify(bad, want_first=True) == (False, want_bad, want_first)
-    dn = par.DistributedNTT(log_n, ops, log_r=log_r)
+    dn = par.DistributedNTT(log_n, ops, log_r=log_r, collectives=coll)
     qh = par.DistributedQapH(shc, dn, orc.generator)
     h, ok = qh.run(dev(ctx, w))
     want_h, want_ok = orc.qap_h(n, m, log_n, *mats, w, nthreads=4)

@@ -456,8 +456,8 @@ def test_hip_ops_distributed_layer_world1(request, acx, field):
 
 def test_distributed_h_2_24_block_system_world1(request, acx):
     """configs[3]'s constraint system (2^24 constraints = 256 block-diagonal 2^16 mulgraph systems) through the
-    distributed pipeline at world size 1: rank-local row marshalling in block-cyclic order, residual dots written in
-    ROWS ownership, 7 four-step transforms (2^12 x 2^12), h in COLS ownership.  Checked by size-independent
+    distributed pipeline at world size 1: rank-local row marshalling in block-cyclic (ascending) order, residual dots written as
+    the transposed ROWS block, 6 four-step transforms (2^12 x 2^12), h in COLS ownership.  Checked by size-independent
     properties: h(x) * (x^N - 1) == L(x) R(x) - O(x) at two random points (Schwartz-Zippel), L/R/O evaluated from the
     first stage's own coefficient vectors; and a corrupted witness is rejected."""
     import torch
@@ -480,7 +480,7 @@ def test_distributed_h_2_24_block_system_world1(request, acx):
     L = dn.local
     dots = torch.zeros((3 * L, 4), dtype=torch.int64, device="cuda")
     sh.verify_dev(dw, dots=dots)
-    coef = [_canon(ctx, dn.inverse(dots[k * L:(k + 1) * L].contiguous())) for k in range(3)]
+    coef = [_canon(ctx, dn.inverse(dots[k * L:(k + 1) * L].contiguous(), rows_t=sh.rows_t)) for k in range(3)]
     idx = dn.cols_indices()
 
     def horner_at(vals_cols, x):

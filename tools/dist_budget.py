@@ -5,8 +5,9 @@ four-step transform take (world, rank) as plain arguments, the rank's block-cycl
 row source, and the all-to-all moves a known number of bytes.  Prints microseconds per local step (HIP events on
 libacx's stream) and the exchange volume, from which the 8-GPU time of one distributed h(x) follows:
 
-    t = residual_dots + 3 * (inv0 + inv1) + 2 * (fwd0c + fwd1) + pointwise + (inv0 + inv1c) + sub_o + 6 * exchange + all-reduce
-(six transforms: O(x) stays in coefficient form)
+    t = residual_dots + 3 * (inv0t + inv1) + 2 * (fwd0c + fwd1) + pointwise + (inv0 + inv1c) + sub_o + 6 * exchange + all-reduce
+(six transforms: O(x) stays in coefficient form; the rank's rows are loaded in ascending order, so the three
+inverse transforms of the dots start from the transposed ROWS block: inv0t)
 
 python tools/dist_budget.py [--world 8] [--logn 24]   (run under rocprofv3 --kernel-trace for the kernel view)"""
 import argparse
@@ -53,12 +54,13 @@ def main():
     ctx.dev_from_canonical(L, x.data_ptr(), x.data_ptr())
     y = torch.empty_like(x)
     t = {}
-    for name, inv, step, shift in (("fwd0", False, 0, None), ("fwd0c", False, 0, g), ("fwd1", False, 1, None),
-                                   ("inv0", True, 0, None), ("inv1", True, 1, None), ("inv1c", True, 1, g)):
-        t[name] = timed(stream, lambda: ctx.ntt_dist_step_dev(x.data_ptr(), y.data_ptr(), ln, lr, W, 0, inv, step, shift))
+    for name, inv, step, shift, rows_t in (("fwd0", False, 0, None, False), ("fwd0c", False, 0, g, False), ("fwd1", False, 1, None, False),
+                                           ("inv0", True, 0, None, False), ("inv0t", True, 0, None, True), ("inv1", True, 1, None, False),
+                                           ("inv1c", True, 1, g, False)):
+        t[name] = timed(stream, lambda: ctx.ntt_dist_step_dev(x.data_ptr(), y.data_ptr(), ln, lr, W, 0, inv, step, shift, rows_t))
     # rank 0's rows of the 2^logn-constraint block system, block-cyclic ownership
     bs = synth.BlockSystem(synth.mulgraph(1 << 16, seed=0xAC4, field=a.field), (1 << ln) >> 16)
-    rows = par.cyclic_rows(ln, lr, W, 0)
+    rows = par.cyclic_rows(ln, lr, W, 0, ascending=True)          # ascending order: the dots come out as the transposed ROWS block
     r = acx.R1CS.load(ctx, rows.shape[0], bs.m, *bs.rows_of(rows))
     w = bs.witness()
     dw = torch.from_numpy(w.view(np.int64).copy()).cuda()
@@ -73,7 +75,7 @@ def main():
     t["pointwise"] = timed(stream, lambda: ctx.qap_pointwise_dev(dots.data_ptr(), dots[L:].data_ptr(), None, y.data_ptr(), L, ln, g))
     t["sub_o"] = timed(stream, lambda: ctx.qap_sub_o_dev(y.data_ptr(), dots[2 * L:].data_ptr(), L, ln, g))
     xbytes = L * 32 * (W - 1) // W
-    local = t["residual_dots"] + 3 * (t["inv0"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["pointwise"] + t["inv0"] + t["inv1c"] + t["sub_o"]
+    local = t["residual_dots"] + 3 * (t["inv0t"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["pointwise"] + t["inv0"] + t["inv1c"] + t["sub_o"]
     print(f"rank-local budget of a {W}-rank job, N = 2^{ln} = 2^{lr} x 2^{ln - lr}, {a.field} Fr, {L} elements per rank (us):")
     for k, v in t.items():
         print(f"  {k:14s} {v:10.1f}")
