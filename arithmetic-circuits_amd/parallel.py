@@ -168,6 +168,9 @@ class HipLocalRows(LocalRows):
     def verify(self, w: torch.Tensor, want_first: bool = False, dots: Optional[torch.Tensor] = None):
         none = 1 << 62
         res_vec = None
+        # libacx launches on its own stream: order it after whatever the caller's stream still has in flight on `w` / `dots`
+        # (e.g. the fill of a freshly allocated torch.zeros buffer), as HipOps._fenced does for the transform steps
+        self._stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._stream):
             self._res.copy_(torch.tensor([0, -1], dtype=torch.int64), non_blocking=False)
             if want_first and not self._monotone:
@@ -462,7 +465,9 @@ class DistributedQapH:
         nt, L = self.ntt, self.ntt.local
         if self._bufs is None:
             dev = w.device if isinstance(w, torch.Tensor) else "cpu"
-            self._bufs = (torch.zeros((3 * L, 4), dtype=torch.int64, device=dev),
+            # no fill: the local system has exactly N/W rows (padding rows are empty rows), so the residual launch writes every
+            # element of the three dot-product vectors
+            self._bufs = (torch.empty((3 * L, 4), dtype=torch.int64, device=dev),
                           torch.empty((3 * L, 4), dtype=torch.int64, device=dev))
         dots, tmp = self._bufs
         verdict, first = self.sharded.dots(w, dots)                       # rows of padding give 0
