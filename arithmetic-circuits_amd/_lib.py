@@ -110,6 +110,7 @@ SYMBOLS = {
     "acx_mgpu_r1cs_destroy": (None, [_P]),
     "acx_mgpu_r1cs_dims": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U32), C.POINTER(_U32)]),
     "acx_mgpu_r1cs_verify": (_I, [_P, _P, C.POINTER(_I), C.POINTER(_U64), C.POINTER(_U64)]),
+    "acx_mgpu_r1cs_verify_many": (_I, [_P, _U64, _P, _P, _P]),
     "acx_mgpu_qap_h": (_I, [_P, _P, _P, _P, C.POINTER(_U64), C.POINTER(_I)]),
     "acx_mgpu_ntt": (_I, [_P, _U32, _I, _P, _P, _P]),
     "acx_mgpu_witness_upload": (_I, [_P, _P]),

@@ -1002,6 +1002,99 @@ int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* mr, uint32_t slot0, uint32_t count, ui
     return ACX_OK;
 }
 
+// `all (verifyAssignment qap) assignments` (test/Test/Circuit/Arithmetic.hs:209) over all devices in one call: every witness is
+// replicated in turn (one copy per GPU, issued asynchronously by the shard's host thread into one of two witness buffers, so
+// witness k+1 crosses PCIe while witness k is being checked), its check accumulates into a ring slot, and the verdicts of up to
+// 16 witnesses are combined by ONE all-reduce.
+int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad) {
+    if (!mr || !ok || (count && !witnesses)) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (count == 0) return ACX_OK;
+    if (!mr->sharded) return acx_r1cs_verify_many(mr->whole, count, witnesses, ok, n_bad, nullptr);
+    acx_mgpu* mg = mr->mg;
+    std::lock_guard<std::mutex> g(mg->mu);
+    DevGuard dg;
+    const uint32_t W = mg->W;
+    mr->witness_resident = false;                   // the resident witness is overwritten
+    mr->h_valid = false;
+    // second witness buffer per shard, allocated on first use
+    std::vector<uint4*> alt(W, nullptr);
+    for (uint32_t s = 0; s < W; ++s) {
+        HIP_TRY(hipSetDevice(mg->sh[s].device));
+        if (hipMalloc((void**)&alt[s], mr->m * 32) != hipSuccess) {
+            for (uint32_t t = 0; t < s; ++t) { (void)hipSetDevice(mg->sh[t].device); (void)hipFree(alt[t]); }
+            return fail(ACX_ERR_OOM, "device allocation failed");
+        }
+    }
+    auto cleanup = [&]() {
+        for (uint32_t s = 0; s < W; ++s) { (void)hipSetDevice(mg->sh[s].device); (void)hipStreamSynchronize(mg->sh[s].ctx->stream); (void)hipFree(alt[s]); }
+    };
+    for (auto& S : mg->sh) {                        // canonicity flag of the whole call
+        HIP_TRY(hipSetDevice(S.device));
+        HIP_TRY(hipMemsetAsync(S.d_res + 2, 0, 4, S.ctx->stream));
+    }
+    int rc = ACX_OK;
+    for (uint64_t done = 0; done < count && rc == ACX_OK; done += kMgRing) {
+        const uint32_t k = (uint32_t)std::min<uint64_t>(kMgRing, count - done);
+        rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+            MgShard& S = mg->sh[s];
+            HIP_TRY(hipSetDevice(S.device));
+            CtxLock lock(S.ctx->mu);
+            const auto& P = mr->part[s];
+            for (uint32_t i = 0; i < k; ++i) {
+                uint4* d_w = ((done + i) & 1) ? alt[s] : P.d_w;
+                // the stream is in order: the check of witness i-2 (same buffer) precedes this copy
+                HIP_TRY(hipMemcpyAsync(d_w, witnesses + (done + i) * mr->m, mr->m * 32, hipMemcpyHostToDevice, S.ctx->stream));
+                ACX_TRY(launch_convert(S.ctx, true, d_w, d_w, mr->m, (uint32_t*)(S.d_res + 2)));
+                ACX_TRY(launch_residual(P.slab, d_w, P.row0, P.ring + 2 * i, nullptr, nullptr, 0));
+            }
+            return ACX_OK;
+        });
+        if (rc != ACX_OK) break;
+        // ONE collective for the k verdicts (the body of acx_mgpu_r1cs_verdicts, slots 0 .. k-1)
+        std::vector<unsigned long long> host(2 * k, 0), init(2 * k);
+        for (uint32_t i = 0; i < k; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
+        std::vector<uint64_t> bad(k, 0);
+        if (mg->rccl) {
+            ncclResult_t r = mg->api->GroupStart();
+            for (uint32_t s = 0; s < W && r == ncclSuccess; ++s)
+                r = mg->api->AllReduce(mr->part[s].ring, mr->part[s].ring + 2 * kMgRing, 2 * k, ncclUint64, ncclSum, mg->sh[s].comm, mg->sh[s].ctx->stream);
+            const ncclResult_t r2 = mg->api->GroupEnd();
+            if (r != ncclSuccess || r2 != ncclSuccess) { rc = fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r != ncclSuccess ? r : r2)); break; }
+            for (uint32_t s = 0; s < W; ++s) {
+                (void)hipSetDevice(mg->sh[s].device);
+                if (s == 0) (void)hipMemcpyAsync(host.data(), mr->part[0].ring + 2 * kMgRing, 16 * k, hipMemcpyDeviceToHost, mg->sh[0].ctx->stream);
+                (void)hipMemcpyAsync(mr->part[s].ring, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
+            }
+            for (uint32_t s = 0; s < W; ++s) { (void)hipSetDevice(mg->sh[s].device); if (hipStreamSynchronize(mg->sh[s].ctx->stream) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream synchronisation failed"); }
+            for (uint32_t i = 0; i < k; ++i) bad[i] = host[2 * i];
+        } else {
+            std::vector<std::vector<unsigned long long>> per(W, std::vector<unsigned long long>(2 * k));
+            for (uint32_t s = 0; s < W; ++s) {
+                (void)hipSetDevice(mg->sh[s].device);
+                (void)hipMemcpyAsync(per[s].data(), mr->part[s].ring, 16 * k, hipMemcpyDeviceToHost, mg->sh[s].ctx->stream);
+                (void)hipMemcpyAsync(mr->part[s].ring, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
+            }
+            for (uint32_t s = 0; s < W; ++s) {
+                (void)hipSetDevice(mg->sh[s].device);
+                if (hipStreamSynchronize(mg->sh[s].ctx->stream) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream synchronisation failed");
+                for (uint32_t i = 0; i < k; ++i) bad[i] += per[s][2 * i];
+            }
+        }
+        for (uint32_t i = 0; i < k && rc == ACX_OK; ++i) {
+            ok[done + i] = bad[i] == 0;
+            if (n_bad) n_bad[done + i] = bad[i];
+        }
+    }
+    if (rc == ACX_OK) {
+        uint32_t flag = 0;
+        (void)hipSetDevice(mg->sh[0].device);
+        if (hipMemcpy(&flag, mg->sh[0].d_res + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ACX_ERR_HIP, "flag fetch failed");
+        else if (flag) rc = fail(ACX_ERR_NONCANONICAL, "element >= p");
+    }
+    cleanup();
+    return rc;
+}
+
 int acx_mgpu_qap_h_resident(acx_mgpu_r1cs* mr, const acx_fr* delta, int* ok) {
     if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");

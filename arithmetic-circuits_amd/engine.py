@@ -496,6 +496,17 @@ class MgR1CS:
         check(self.mg.lib.acx_mgpu_r1cs_verify(self._h, _ptr(w), C.byref(ok), C.byref(nbad), C.byref(first) if want_first else None))
         return bool(ok.value), nbad.value, first.value
 
+    def verify_many(self, witnesses: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """`all (verifyAssignment qap) assignments` in one call: witnesses (count, m, 4) canonical -> (ok[count] bool, n_bad[count])."""
+        w = np.ascontiguousarray(witnesses, dtype=np.uint64)
+        if w.ndim != 3 or w.shape[1:] != (self.m, 4):
+            raise ValueError(f"witnesses must have shape (count, {self.m}, 4)")
+        count = w.shape[0]
+        ok = np.zeros(count, dtype=np.uint8)
+        nbad = np.zeros(count, dtype=np.uint64)
+        check(self.mg.lib.acx_mgpu_r1cs_verify_many(self._h, count, w.ctypes.data if count else None, ok.ctypes.data, nbad.ctypes.data))
+        return ok.astype(bool), nbad
+
     def qap_h(self, witness: np.ndarray, delta: Optional[Sequence[int]] = None) -> Tuple[Optional[np.ndarray], bool]:
         w = _fr_array(witness, self.m)
         out = np.zeros(((1 << self.log_n) + 1, 4), dtype=np.uint64)

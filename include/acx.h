@@ -378,6 +378,11 @@ int acx_mgpu_r1cs_dims(const acx_mgpu_r1cs* r, uint64_t* n, uint64_t* m, uint32_
 /* `verifyAssignment` (src/QAP.hs:276-282) over all devices: arguments and results of acx_r1cs_verify (first_bad = the smallest
  * violated GLOBAL row; passing NULL saves the second all-reduce of a failing check). */
 int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad);
+/* `all (verifyAssignment qap) assignments` (test/Test/Circuit/Arithmetic.hs:200-209) over all devices in ONE call: witnesses =
+ * count x m canonical elements; ok[k] (and n_bad[k] when given) as acx_mgpu_r1cs_verify reports them.  Witness k+1 crosses PCIe
+ * while witness k is checked; the verdicts of up to 16 witnesses share one all-reduce.  Any non-canonical element fails the
+ * whole call with ACX_ERR_NONCANONICAL. */
+int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* r, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad);
 /* `verificationWitnessZk` (src/QAP.hs:300-327) over all devices: arguments and results of acx_qap_h (out_h holds N + 1 elements). */
 int acx_mgpu_qap_h(acx_mgpu_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok);
 /* `FFT.fft` / `FFT.interpolate` (galois-fft; src/QAP.hs:521-524) of ONE 2^log_n-point vector spread over the devices: host data

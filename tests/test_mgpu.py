@@ -85,9 +85,19 @@ def test_mgpu_verify_and_h_equal_single_gpu_and_oracle(acx, request, field, devi
     assert mr.verdicts(0, 16).tolist() == [0] * 16              # read slots are cleared
     r1.close()
     mr.close()
+    # many assignments in one call (more than one ring of 16, valid and corrupted interleaved)
+    many = np.stack([bad if k % 3 == 1 else w for k in range(37)])
     # verification-only load: no block-cyclic copy, h(x) is refused, the verdict is the same
     mv = mg.from_circuit(s.circuit, verify_only=True)
     assert mv.verify(bad) == (False, nbad, first) and mv.verify(w) == (True, 0, U64_MAX)
+    oks, nbads = mv.verify_many(many)
+    assert oks.tolist() == [k % 3 != 1 for k in range(37)] and nbads.tolist() == [nbad if k % 3 == 1 else 0 for k in range(37)]
+    assert mv.verify_many(many[:0])[0].shape == (0,)
+    many[20, 7] = np.array([U64_MAX] * 4, dtype=np.uint64)
+    with pytest.raises(acx.AcxError) as e:
+        mv.verify_many(many)
+    assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
+    assert mv.verify(w) == (True, 0, U64_MAX)                   # the handle is usable after the failed call
     with pytest.raises(acx.AcxError) as e:
         mv.qap_h(w)
     assert e.value.status == acx._lib.STATUS["UNSUPPORTED"]

@@ -20,10 +20,9 @@ from oracle.c_oracle import COracle
 
 DEFAULT_VARIANTS = [
     "tile=ACX_NTT_IMPL=tile",
-    "r4-lds=ACX_NTT_IMPL=r4,ACX_NTT_XCHG=lds",
-    "r4-dpp=ACX_NTT_IMPL=r4,ACX_NTT_XCHG=dpp",
+    "r4=ACX_NTT_IMPL=r4",
 ]
-KEYS = ["ACX_NTT_IMPL", "ACX_NTT_XCHG", "ACX_NTT_TILE_LOG", "ACX_NTT_DIRECT_TW", "ACX_NTT_DIGITS"]
+KEYS = ["ACX_NTT_IMPL", "ACX_NTT_TILE_LOG", "ACX_NTT_DIRECT_TW", "ACX_NTT_DIGITS"]
 
 
 def make_ctx(spec, field):

@@ -2,6 +2,6 @@
 for spec in "$@"; do
   for s in $spec; do
     ln=${s%%:*}; d=${s##*:}
-    python tools/ntt_ab.py --no-check --sizes $ln --batch-sizes --variants "d$d=ACX_NTT_DIGITS=$d" "d$d-dpp=ACX_NTT_DIGITS=$d,ACX_NTT_XCHG=dpp" 2>&1 | grep bn254
+    python tools/ntt_ab.py --no-check --sizes $ln --batch-sizes --variants "d$d=ACX_NTT_DIGITS=$d" 2>&1 | grep bn254
   done
 done
