@@ -350,7 +350,10 @@ int mg_upload_witness(acx_mgpu_r1cs* mr, const acx_fr* witness) {
 }
 
 // residual launch on every shard (+ dots when the h(x) pipeline follows) and the verdict.
-int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_bad, uint64_t* first_bad, bool* noncanonical) {
+// Two halves, so that h(x) can issue its whole pipeline between them and the host waits once, at the end.
+// mg_residual_enqueue: the residual launch on every shard (+ dots when the h(x) pipeline follows) and, with RCCL, THE verdict
+// collective behind it -- everything asynchronous.  mg_residual_fetch: the verdict (one wait).
+int mg_residual_enqueue(acx_mgpu_r1cs* mr, bool with_dots) {
     acx_mgpu* mg = mr->mg;
     const uint32_t W = mg->W;
     const uint64_t L = (1ull << mr->log_n) / W, rw = (1ull << mr->log_r) / W;
@@ -366,8 +369,6 @@ int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_
         else
             ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, S.d_res, nullptr, nullptr, 0));
     }
-    CallSlot slot0;
-    unsigned long long total = 0, first = ~0ull;
     if (mg->rccl) {
         // THE verdict collective: sum of the violated-row counts, into word 4 of every shard's slot
         NCCL_TRY(mg, mg->api->GroupStart());
@@ -376,6 +377,16 @@ int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_
             if (r != ncclSuccess) { (void)mg->api->GroupEnd(); return fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r)); }
         }
         NCCL_TRY(mg, mg->api->GroupEnd());
+    }
+    return ACX_OK;
+}
+
+int mg_residual_fetch(acx_mgpu_r1cs* mr, bool want_first, uint64_t* n_bad, uint64_t* first_bad, bool* noncanonical) {
+    acx_mgpu* mg = mr->mg;
+    const uint32_t W = mg->W;
+    CallSlot slot0;
+    unsigned long long total = 0, first = ~0ull;
+    if (mg->rccl) {
         MgShard& S0 = mg->sh[0];
         HIP_TRY(hipSetDevice(S0.device));
         HIP_TRY(hipMemcpyAsync(&slot0, S0.d_res, sizeof(slot0), hipMemcpyDeviceToHost, S0.ctx->stream));
@@ -410,6 +421,11 @@ int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_
     *n_bad = total;
     *first_bad = (total != 0 && want_first) ? first : ~0ull;
     return ACX_OK;
+}
+
+int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_bad, uint64_t* first_bad, bool* noncanonical) {
+    ACX_TRY(mg_residual_enqueue(mr, with_dots));
+    return mg_residual_fetch(mr, want_first, n_bad, first_bad, noncanonical);
 }
 
 // [rows][cols] -> [cols][rows] of 32-byte elements through a 32 x 32 LDS tile, with the canonical <-> dev conversion of the
@@ -646,10 +662,7 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
             HIP_TRY(hipMalloc((void**)&mr->part[s].vec, 8 * L * 32));
         }
     mr->h_valid = false;
-    uint64_t n_bad = 0, first = 0;
-    bool noncanon = false;
-    ACX_TRY(mg_residual(mr, true, false, &n_bad, &first, &noncanon));
-    if (noncanon) return fail(ACX_ERR_NONCANONICAL, "element >= p");
+    ACX_TRY(mg_residual_enqueue(mr, true));         // the verdict is fetched after the whole pipeline has been issued: one wait
     const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
     const H256 g = hf.generator();
     MgNtt nt(mg, mr->log_n, mr->log_r);
@@ -700,6 +713,10 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
         }
         HIP_TRY(hipGetLastError());
     }
+    uint64_t n_bad = 0, first = 0;
+    bool noncanon = false;
+    ACX_TRY(mg_residual_fetch(mr, false, &n_bad, &first, &noncanon));
+    if (noncanon) return fail(ACX_ERR_NONCANONICAL, "element >= p");
     mr->h_top = zk ? hf.mul(dl[0], dl[1]) : hf.zero();
     mr->h_valid = true;
     *ok = n_bad == 0;
