@@ -2427,4 +2427,20 @@ int acx_ntt_dev(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const a
 
 }  // extern "C"
 
+#ifdef ACX_K2_TRACE
+// development build only (tools/k2_trace.py): read and clear the residual kernel's phase accumulators
+extern "C" int acx_debug_k2_trace(unsigned long long out[16]) {
+    static std::vector<unsigned long long> host(2ull * acx::kK2TraceWaves * 6);
+    if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(acx::g_k2_trace), host.size() * 8) != hipSuccess) return ACX_ERR_HIP;
+    for (int r = 0; r < 2; ++r) {
+        for (int k = 0; k < 8; ++k) out[8 * r + k] = 0;
+        for (uint64_t i = 0; i < acx::kK2TraceWaves; ++i)
+            for (int k = 0; k < 6; ++k) out[8 * r + k] += host[((uint64_t)r * acx::kK2TraceWaves + i) * 6 + k];
+    }
+    std::fill(host.begin(), host.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(acx::g_k2_trace), host.data(), host.size() * 8) != hipSuccess) return ACX_ERR_HIP;
+    return ACX_OK;
+}
+#endif
+
 #include "mgpu.inc.h"

@@ -157,13 +157,34 @@ __global__ __launch_bounds__(kBlock) void k_build_sell_small(CsrDev M, const u32
     }
 }
 
+#ifdef ACX_K2_TRACE
+// Development build (tools/k2_trace.py): where a wave of the residual kernel spends its life.  Per role (A wave / B-C-closing
+// wave) the SUM over all waves of: [0] waves, [1] cycles until the descriptor is in registers, [2] until the slice offsets are,
+// [3] until the first slot's stream words have arrived, [4] until the dot product of the first matrix is reduced, [5] total.
+constexpr u32 kK2TraceWaves = 1u << 16;               // one record per workgroup and role: plain stores (same-address atomics from
+__device__ unsigned long long g_k2_trace[2][kK2TraceWaves][6];   // 65536 waves serialise at ~10 per us and would distort what is measured)
+__device__ __forceinline__ u64 k2_now() { return __builtin_readcyclecounter(); }
+struct K2Trace { u64 t0, t_desc, t_ofs, t_first, t_dot; };
+#define K2_TRACE_ARG , K2Trace* tr
+#define K2_TRACE_PASS(x) , x
+#else
+#define K2_TRACE_ARG
+#define K2_TRACE_PASS(x)
+#endif
+
+// slots [q0, q1) of one slice.  UNIT: c_first = the column word of slot q0 when the caller has loaded it already (the closer
+// wave requests it at its start, under <B,w>: the dot product of a unit C is then one gather away instead of a stream round
+// trip plus a gather), have_first says so.
 template <class F, bool UNIT>
-__device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane) {
-    const u32 q0 = sload(M.slice_ofs + slice), q1 = sload(M.slice_ofs + slice + 1);   // wave-uniform: scalar loads
+__device__ __forceinline__ Fe sell_dot_range(const SellDev& M, const uint4* __restrict__ w, u32 q0, u32 q1, u32 lane, u32 c_first,
+                                             bool have_first K2_TRACE_ARG) {
+#ifdef ACX_K2_TRACE
+    if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(q0), "s"(q1)); tr->t_ofs = k2_now(); }
+#endif
     Fe acc = fe_zero();
     if (UNIT) {
         for (u32 q = q0; q < q1; ++q) {
-            const u32 c = gload(&M.tail[(u64)q * kSlice + lane]).y;
+            const u32 c = (have_first && q == q0) ? c_first : gload(&M.tail[(u64)q * kSlice + lane]).y;
             if (c != kNoRow) {
                 const Fe x = fe_gload(w + 2 * (u64)c);
                 acc = (q == q0) ? x : fe_add<F>(acc, x);    // rows are sorted: padding never precedes data
@@ -187,6 +208,9 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
     uint2 t = nt_load(&M.tail[(u64)q0 * kSlice + lane]);
     uint4 lo = nt_load(&M.val[(2 * (u64)q0) * kSlice + lane]);
     uint4 hi = nt_load(&M.val[(2 * (u64)q0 + 1) * kSlice + lane]);
+#ifdef ACX_K2_TRACE
+    if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(t.y), "v"(hi.w)); tr->t_first = k2_now(); }
+#endif
     for (u32 q = q0; q < q1; ++q) {
         const uint4* px = w + 2 * (u64)(t.y == kNoRow ? 0u : t.y);   // padding: value 0 * w[0]
         const uint4 xlo = gload(px), xhi = gload(px + 1);
@@ -204,6 +228,12 @@ __device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict
         if (q == q0) wide_mul(wide, v, x); else wide_mac(wide, v, x);
     }
     return wide_reduce<F>(wide);
+}
+
+template <class F, bool UNIT>
+__device__ __forceinline__ Fe sell_dot(const SellDev& M, const uint4* __restrict__ w, u32 slice, u32 lane K2_TRACE_ARG) {
+    const u32 q0 = sload(M.slice_ofs + slice), q1 = sload(M.slice_ofs + slice + 1);   // wave-uniform: scalar loads
+    return sell_dot_range<F, UNIT>(M, w, q0, q1, lane, kNoRow, false K2_TRACE_PASS(tr));
 }
 
 // <M_row, w> for a small-coefficient matrix: nine signed columns, one v_mad_i64_i32 per limb and entry, one exact
@@ -335,33 +365,76 @@ __device__ __forceinline__ SellSystem sell_system_of_launch(const SellSystem* sy
 // (A + closing | B | C) 118.1, two waves (A + closing | B, C) 115.2, this form 114.7.
 template <class F, int SPEC = 0>
 __global__ __launch_bounds__(2 * kSlice) void k_r1cs_sell_split(const SellSystem* __restrict__ systems, SellSystem one) {
+#ifdef ACX_K2_TRACE
+    K2Trace trace{k2_now(), 0, 0, 0, 0};
+    K2Trace* tr = &trace;
+#endif
     const SellSystem S = sell_system_of_launch(systems, one);               // batched : single
     const u32 per_xcd = (S.n_slices + 7) / 8;
     const u32 slice = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (blockIdx.x >= 8 * per_xcd || slice >= S.n_slices) return;          // uniform over the workgroup
+#ifdef ACX_K2_TRACE
+    trace.t_desc = k2_now();
+#endif
     const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kSlice), lane = threadIdx.x % kSlice;
     constexpr bool kMixed = SPEC == 2;
     __shared__ u32 park[2][kLimbs][kSlice];
     Fe b = fe_zero(), c = b;
     u32 row = kNoRow;
     if (wv == 0) {
-        const Fe a = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane);
+        const Fe a = (SPEC == 1 || (kMixed && (S.small & 1u))) ? sell_dot_small<F>(S.A, S.w, slice, lane) : sell_dot<F, false>(S.A, S.w, slice, lane K2_TRACE_PASS(tr));
+#ifdef ACX_K2_TRACE
+        asm volatile("" ::"v"(a.l[0]));
+        trace.t_dot = k2_now();
+#endif
 #pragma unroll
         for (int i = 0; i < kLimbs; ++i) park[0][i][lane] = a.l[i];
     } else {
         row = gload(S.perm + slice * kSlice + lane);                        // needed last: issued first
-        b = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane);
+        // A unit C (every gate the reference emits) is one column word and one gather per entry.  Its slot range and the
+        // column word of its first slot are requested NOW, under <B,w>: a wave's life is a chain of ~3000-cycle memory
+        // round trips (tools/k2_trace.py: 20.4k cycles for this wave, of which the C phase's own offsets + column word +
+        // gather were ~5.5k), and this takes two of them out of the chain for one more register.
+        const bool unit_c = SPEC == 1 || S.unit_c;
+        u32 qc0 = 0, qc1 = 0, c_first = kNoRow;
+        if (unit_c) {
+            qc0 = sload(S.C.slice_ofs + slice); qc1 = sload(S.C.slice_ofs + slice + 1);
+            if (qc0 < qc1) c_first = gload(&S.C.tail[(u64)qc0 * kSlice + lane]).y;
+        }
+        b = (SPEC == 1 || (kMixed && (S.small & 2u))) ? sell_dot_small<F>(S.B, S.w, slice, lane) : sell_dot<F, false>(S.B, S.w, slice, lane K2_TRACE_PASS(tr));
+#ifdef ACX_K2_TRACE
+        asm volatile("" ::"v"(b.l[0]));
+        trace.t_dot = k2_now();
+#endif
 #pragma unroll
         for (int i = 0; i < kLimbs; ++i) park[1][i][lane] = b.l[i];         // own wave's LDS traffic is ordered: no barrier
-        c = (SPEC == 1 || S.unit_c) ? sell_dot<F, true>(S.C, S.w, slice, lane)
-            : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane);
+        c = unit_c ? sell_dot_range<F, true>(S.C, S.w, qc0, qc1, lane, c_first, true K2_TRACE_PASS(nullptr))
+            : (kMixed && (S.small & 4u)) ? sell_dot_small<F>(S.C, S.w, slice, lane) : sell_dot<F, false>(S.C, S.w, slice, lane K2_TRACE_PASS(nullptr));
     }
+#ifdef ACX_K2_TRACE
+    auto k2_flush = [&](u32 role) {
+        if (lane == 0) {
+            const u64 t_end = k2_now();
+            unsigned long long* rec = g_k2_trace[role][(blockIdx.y * gridDim.x + blockIdx.x) & (kK2TraceWaves - 1)];
+            rec[0] = 1ull;
+            rec[1] = trace.t_desc - trace.t0;
+            rec[2] = trace.t_ofs - trace.t0;
+            rec[3] = trace.t_first - trace.t0;
+            rec[4] = trace.t_dot - trace.t0;
+            rec[5] = t_end - trace.t0;
+        }
+    };
+    if (wv == 0) k2_flush(0);
+#endif
     __syncthreads();
     if (wv == 0) return;
     Fe a;
 #pragma unroll
     for (int i = 0; i < kLimbs; ++i) { a.l[i] = park[0][i][lane]; b.l[i] = park[1][i][lane]; }
     residual_epilogue<F>(a, b, c, row, row != kNoRow, S.out);
+#ifdef ACX_K2_TRACE
+    k2_flush(1);
+#endif
 }
 
 // CSR path for the listed rows only (rows too long for the SELL layout: the 2^j row of a Split gate has 257 entries,
