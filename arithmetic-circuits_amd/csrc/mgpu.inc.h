@@ -533,14 +533,17 @@ void mg_gather_rows(const acx_csr& M, uint64_t n, uint32_t log_n, uint32_t log_r
     }
     out.col.resize(nnz);
     out.val.resize(nnz);
-    for (uint64_t j = 0; j < L; ++j) {
-        const uint64_t row = global_row(j);
-        if (row >= n) continue;
-        const uint32_t e0 = M.rowptr[row], len = M.rowptr[row + 1] - e0;
-        if (len == 0) continue;
-        std::memcpy(&out.col[out.rowptr[j]], M.col + e0, (size_t)len * 4);
-        std::memcpy(&out.val[out.rowptr[j]], M.val + e0, (size_t)len * 32);
-    }
+    // the copies run on a few worker threads per shard (the shards themselves are gathered concurrently, one thread each)
+    parallel_ranges(L, std::min(8u, host_threads(L, 1 << 16)), [&](unsigned, uint64_t jb, uint64_t je) {
+        for (uint64_t j = jb; j < je; ++j) {
+            const uint64_t row = global_row(j);
+            if (row >= n) continue;
+            const uint32_t e0 = M.rowptr[row], len = M.rowptr[row + 1] - e0;
+            if (len == 0) continue;
+            std::memcpy(&out.col[out.rowptr[j]], M.col + e0, (size_t)len * 4);
+            std::memcpy(&out.val[out.rowptr[j]], M.val + e0, (size_t)len * 32);
+        }
+    });
 }
 
 void mg_free_r1cs(acx_mgpu_r1cs* mr) {
@@ -583,8 +586,12 @@ int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], 
     for (int k = 0; k < 3; ++k) {
         if (!mats[k] || !mats[k]->rowptr) return fail(ACX_ERR_INVALID_ARG, "null CSR");
         if (mats[k]->rowptr[0] != 0) return fail(ACX_ERR_INVALID_ARG, "rowptr[0] != 0");
-        for (uint64_t i = 0; i < n; ++i)
-            if (mats[k]->rowptr[i + 1] < mats[k]->rowptr[i]) return fail(ACX_ERR_INVALID_ARG, "rowptr not monotone");
+        std::atomic<bool> bad{false};                          // checked before any row is gathered: the gathers trust the row pointers
+        parallel_ranges(n, host_threads(n, 1 << 18), [&](unsigned, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i)
+                if (mats[k]->rowptr[i + 1] < mats[k]->rowptr[i]) { bad = true; return; }
+        });
+        if (bad) return fail(ACX_ERR_INVALID_ARG, "rowptr not monotone");
         if (mats[k]->rowptr[n] && (!mats[k]->col || !mats[k]->val)) return fail(ACX_ERR_INVALID_ARG, "null CSR arrays");
     }
     std::unique_ptr<acx_mgpu_r1cs> mr(new acx_mgpu_r1cs());
