@@ -250,3 +250,47 @@ def test_mgpu_configs3_2_24_constraints_through_rccl(acx, request):
     assert nbad > 0 and mr.verify(bad) == (False, nbad, first)
     assert mr.qap_h(bad) == (None, False)
     mr.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0, 0]], ids=lambda d: f"W{len(d)}")
+def test_mgpu_calls_from_several_threads(acx, request, devices):
+    """Haskell `safe` foreign calls arrive from arbitrary OS threads: one handle, four threads, each
+    alternating verifyAssignment on a good and a bad witness and the quotient; every answer equals the serial one (the
+    handle serialises the calls: its collectives must be issued in one order on every device)."""
+    import threading
+    synth = acx.synth
+    mg = _mg(acx, request, "bn254", devices)
+    mg.set_shard_threshold(10)
+    n = 1 << 12
+    s = synth.mulgraph(n, n_in=32, window=256, seed=0x7EAD, field="bn254")
+    w = s.witness()
+    mr = mg.from_circuit(s.circuit)
+    bads = []
+    for k in range(4):
+        b = w.copy()
+        b[1 + 32 + 97 * (k + 1), 0] ^= np.uint64(1 << k)
+        bads.append(b)
+    want_bad = [mr.verify(b) for b in bads]
+    want_h, ok = mr.qap_h(w)
+    assert ok and all(not v[0] and v[1] > 0 for v in want_bad)
+    errors = []
+
+    def worker(k):
+        try:
+            for it in range(6):
+                assert mr.verify(w) == (True, 0, U64_MAX)
+                assert mr.verify(bads[k]) == want_bad[k]
+                if it % 2 == 0:
+                    h, okk = mr.qap_h(w)
+                    assert okk and np.array_equal(h, want_h)
+                else:
+                    assert mr.qap_h(bads[k]) == (None, False)
+        except Exception as e:                       # assertions inside threads are otherwise lost
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
