@@ -113,6 +113,7 @@ SYMBOLS = {
     "acx_mgpu_r1cs_verify_many": (_I, [_P, _U64, _P, _P, _P]),
     "acx_mgpu_qap_h": (_I, [_P, _P, _P, _P, C.POINTER(_U64), C.POINTER(_I)]),
     "acx_mgpu_ntt": (_I, [_P, _U32, _I, _P, _P, _P]),
+    "acx_mgpu_qap_columns": (_I, [_P, _I, _U64, _U64, _P, _P]),
     "acx_mgpu_witness_upload": (_I, [_P, _P]),
     "acx_mgpu_r1cs_verify_resident": (_I, [_P, C.POINTER(_I), C.POINTER(_U64), C.POINTER(_U64)]),
     "acx_mgpu_qap_h_resident": (_I, [_P, _P, C.POINTER(_I)]),

@@ -147,6 +147,7 @@ struct acx_mgpu_r1cs {
         acx_r1cs* slab = nullptr;                   // rows [row0, row0 + slab->n): what verifyAssignment runs on
         uint64_t row0 = 0;
         acx_r1cs* cyc = nullptr;                    // this shard's N/W block-cyclic rows in ascending order: what h(x) runs on (null: verify only)
+        acx_r1cs* full = nullptr;                   // the WHOLE system, for this shard's wires of acx_mgpu_qap_columns (built on its first call)
         uint4* d_w = nullptr;                       // the replicated witness, m dev elements
         uint4* vec = nullptr;                       // h(x) pipeline: dots 3L | coef 3L | pw L | h L (allocated on first use)
         unsigned long long* ring = nullptr;         // kMgRing result slots {n_bad, first_bad} of the asynchronous form + their reduction
@@ -554,6 +555,7 @@ void mg_free_r1cs(acx_mgpu_r1cs* mr) {
         auto& p = mr->part[s];
         if (p.slab) acx_r1cs_destroy(p.slab);                         // synchronises that device
         if (p.cyc) acx_r1cs_destroy(p.cyc);
+        if (p.full) acx_r1cs_destroy(p.full);
         (void)hipSetDevice(mg->sh[s].device);
         if (p.d_w) (void)hipFree(p.d_w);
         if (p.vec) (void)hipFree(p.vec);
@@ -651,6 +653,58 @@ int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], 
     if (rc != ACX_OK) { mg_free_r1cs(mr.release()); return rc; }
     *out = mr.release();
     return ACX_OK;
+}
+
+// Per-wire polynomials (`createPolynomialsFFT`, src/QAP.hs:512-525) shard by WIRE with no communication: a
+// column's interpolation needs every row of its matrix, so each shard takes a copy of the whole system.  Only callers
+// of acx_mgpu_qap_columns pay for that, on their first call: the slabs are read back from the devices (canonical CSR,
+// acx_r1cs_export), joined on the host and loaded on every shard by one thread each.
+int mg_ensure_replicas(acx_mgpu_r1cs* mr) {
+    acx_mgpu* mg = mr->mg;
+    const uint32_t W = mg->W;
+    if (!mr->sharded || mr->part[0].full) return ACX_OK;
+    const uint64_t n = mr->n;
+    std::vector<uint64_t> nnz0[3];                  // entry offset of every slab in the joined matrix
+    for (int k = 0; k < 3; ++k) nnz0[k].assign(W + 1, 0);
+    for (uint32_t s = 0; s < W; ++s) {
+        uint64_t z[3] = {0, 0, 0};
+        ACX_TRY(acx_r1cs_dims(mr->part[s].slab, nullptr, nullptr, nullptr, z));
+        for (int k = 0; k < 3; ++k) nnz0[k][s + 1] = nnz0[k][s] + z[k];
+    }
+    std::vector<uint32_t> rowptr[3], col[3];
+    std::vector<acx_fr> val[3];
+    for (int k = 0; k < 3; ++k) {
+        if (nnz0[k][W] >= 0xffffffffull) return fail(ACX_ERR_TOO_LARGE, "matrix has 2^32 entries or more");
+        rowptr[k].assign(n + 1, 0);
+        col[k].resize(nnz0[k][W]);
+        val[k].resize(nnz0[k][W]);
+    }
+    ACX_TRY(mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+        const auto& P = mr->part[s];
+        uint64_t rows = 0;
+        ACX_TRY(acx_r1cs_dims(P.slab, &rows, nullptr, nullptr, nullptr));
+        std::vector<uint32_t> rp(rows + 1);
+        for (int k = 0; k < 3; ++k) {
+            const uint64_t e0 = nnz0[k][s];
+            ACX_TRY(acx_r1cs_export(P.slab, k, rp.data(), col[k].data() + e0, val[k].data() + e0));
+            for (uint64_t i = 1; i <= rows; ++i) rowptr[k][P.row0 + i] = (uint32_t)(e0 + rp[i]);   // slabs are disjoint row ranges
+        }
+        return ACX_OK;
+    }));
+    acx_csr views[3];
+    const acx_csr* mp[3];
+    for (int k = 0; k < 3; ++k) {
+        views[k] = acx_csr{rowptr[k].data(), col[k].data(), val[k].data()};
+        mp[k] = &views[k];
+    }
+    const int rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+        HIP_TRY(hipSetDevice(mg->sh[s].device));
+        return r1cs_from_host(mg->sh[s].ctx, n, mr->m, mp, &mr->part[s].full);
+    });
+    if (rc != ACX_OK)
+        for (auto& P : mr->part)
+            if (P.full) { acx_r1cs_destroy(P.full); P.full = nullptr; }
+    return rc;
 }
 
 // verificationWitnessZk over the shards on the resident witness; h stays on the devices in COLS ownership
@@ -840,18 +894,22 @@ int acx_mgpu_set_shard_threshold(acx_mgpu* mg, uint32_t log_n) {
 }
 
 int acx_mgpu_set_root(acx_mgpu* mg, uint32_t two_adicity, const acx_fr* omega) {
-    if (!mg) return fail(ACX_ERR_INVALID_ARG, "null handle");
-    std::lock_guard<std::mutex> g(mg->mu);
-    DevGuard dg;
-    for (auto& S : mg->sh) ACX_TRY(acx_ctx_set_root(S.ctx, two_adicity, omega));
-    return ACX_OK;
+    return guarded([&]() -> int {
+        if (!mg) return fail(ACX_ERR_INVALID_ARG, "null handle");
+        std::lock_guard<std::mutex> g(mg->mu);
+        DevGuard dg;
+        for (auto& S : mg->sh) ACX_TRY(acx_ctx_set_root(S.ctx, two_adicity, omega));
+        return ACX_OK;
+    });
 }
 
 int acx_mgpu_sync(acx_mgpu* mg) {
-    if (!mg) return fail(ACX_ERR_INVALID_ARG, "null handle");
-    std::lock_guard<std::mutex> g(mg->mu);
-    DevGuard dg;
-    return mg_sync(mg);
+    return guarded([&]() -> int {
+        if (!mg) return fail(ACX_ERR_INVALID_ARG, "null handle");
+        std::lock_guard<std::mutex> g(mg->mu);
+        DevGuard dg;
+        return mg_sync(mg);
+    });
 }
 
 int acx_mgpu_r1cs_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C, uint32_t flags,
@@ -914,116 +972,126 @@ int acx_mgpu_r1cs_dims(const acx_mgpu_r1cs* mr, uint64_t* n, uint64_t* m, uint32
 }
 
 int acx_mgpu_witness_upload(acx_mgpu_r1cs* mr, const acx_fr* witness) {
-    if (!mr || !witness) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "system is held whole on shard 0 (below the shard threshold): use the host-buffer calls");
-    std::lock_guard<std::mutex> g(mr->mg->mu);
-    DevGuard dg;
-    ACX_TRY(mg_upload_witness(mr, witness));
-    ACX_TRY(mg_sync(mr->mg));
-    for (auto& S : mr->mg->sh) {
-        uint32_t flag = 0;
-        HIP_TRY(hipSetDevice(S.device));
-        HIP_TRY(hipMemcpy(&flag, S.d_res + 2, 4, hipMemcpyDeviceToHost));
-        if (flag) { mr->witness_resident = false; return fail(ACX_ERR_NONCANONICAL, "element >= p"); }
-    }
-    return ACX_OK;
+    return guarded([&]() -> int {
+        if (!mr || !witness) return fail(ACX_ERR_INVALID_ARG, "null argument");
+        if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "system is held whole on shard 0 (below the shard threshold): use the host-buffer calls");
+        std::lock_guard<std::mutex> g(mr->mg->mu);
+        DevGuard dg;
+        ACX_TRY(mg_upload_witness(mr, witness));
+        ACX_TRY(mg_sync(mr->mg));
+        for (auto& S : mr->mg->sh) {
+            uint32_t flag = 0;
+            HIP_TRY(hipSetDevice(S.device));
+            HIP_TRY(hipMemcpy(&flag, S.d_res + 2, 4, hipMemcpyDeviceToHost));
+            if (flag) { mr->witness_resident = false; return fail(ACX_ERR_NONCANONICAL, "element >= p"); }
+        }
+        return ACX_OK;
+    });
 }
 
 int acx_mgpu_r1cs_verify_resident(acx_mgpu_r1cs* mr, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
-    if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
-    std::lock_guard<std::mutex> g(mr->mg->mu);
-    DevGuard dg;
-    uint64_t bad = 0, first = ~0ull;
-    bool noncanon = false;
-    ACX_TRY(mg_residual(mr, false, first_bad != nullptr, &bad, &first, &noncanon));
-    *ok = bad == 0;
-    if (n_bad) *n_bad = bad;
-    if (first_bad) *first_bad = first;
-    return ACX_OK;
+    return guarded([&]() -> int {
+        if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
+        if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
+        std::lock_guard<std::mutex> g(mr->mg->mu);
+        DevGuard dg;
+        uint64_t bad = 0, first = ~0ull;
+        bool noncanon = false;
+        ACX_TRY(mg_residual(mr, false, first_bad != nullptr, &bad, &first, &noncanon));
+        *ok = bad == 0;
+        if (n_bad) *n_bad = bad;
+        if (first_bad) *first_bad = first;
+        return ACX_OK;
+    });
 }
 
 int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* mr, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
-    if (!mr || !witness || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (!mr->sharded) return acx_r1cs_verify(mr->whole, witness, ok, n_bad, first_bad);
-    std::lock_guard<std::mutex> g(mr->mg->mu);
-    DevGuard dg;
-    ACX_TRY(mg_upload_witness(mr, witness));
-    uint64_t bad = 0, first = ~0ull;
-    bool noncanon = false;
-    ACX_TRY(mg_residual(mr, false, first_bad != nullptr, &bad, &first, &noncanon));
-    if (noncanon) { mr->witness_resident = false; return fail(ACX_ERR_NONCANONICAL, "element >= p"); }
-    *ok = bad == 0;
-    if (n_bad) *n_bad = bad;
-    if (first_bad) *first_bad = first;
-    return ACX_OK;
+    return guarded([&]() -> int {
+        if (!mr || !witness || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
+        if (!mr->sharded) return acx_r1cs_verify(mr->whole, witness, ok, n_bad, first_bad);
+        std::lock_guard<std::mutex> g(mr->mg->mu);
+        DevGuard dg;
+        ACX_TRY(mg_upload_witness(mr, witness));
+        uint64_t bad = 0, first = ~0ull;
+        bool noncanon = false;
+        ACX_TRY(mg_residual(mr, false, first_bad != nullptr, &bad, &first, &noncanon));
+        if (noncanon) { mr->witness_resident = false; return fail(ACX_ERR_NONCANONICAL, "element >= p"); }
+        *ok = bad == 0;
+        if (n_bad) *n_bad = bad;
+        if (first_bad) *first_bad = first;
+        return ACX_OK;
+    });
 }
 
 // Throughput form of the resident check: enqueue accumulates the violated-row count of ONE verification into ring slot
 // `slot` on every device and returns at once; verdicts reduces a range of slots with ONE collective and waits.
 int acx_mgpu_r1cs_verify_enqueue(acx_mgpu_r1cs* mr, uint32_t slot) {
-    if (!mr || slot >= kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot < 16)");
-    if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
-    acx_mgpu* mg = mr->mg;
-    std::lock_guard<std::mutex> g(mg->mu);
-    DevGuard dg;
-    for (uint32_t s = 0; s < mg->W; ++s) {
-        MgShard& S = mg->sh[s];
-        HIP_TRY(hipSetDevice(S.device));
-        CtxLock lock(S.ctx->mu);
-        const auto& P = mr->part[s];
-        ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, P.ring + 2 * slot, nullptr, nullptr, 0));
-    }
-    return ACX_OK;
+    return guarded([&]() -> int {
+        if (!mr || slot >= kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot < 16)");
+        if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
+        acx_mgpu* mg = mr->mg;
+        std::lock_guard<std::mutex> g(mg->mu);
+        DevGuard dg;
+        for (uint32_t s = 0; s < mg->W; ++s) {
+            MgShard& S = mg->sh[s];
+            HIP_TRY(hipSetDevice(S.device));
+            CtxLock lock(S.ctx->mu);
+            const auto& P = mr->part[s];
+            ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, P.ring + 2 * slot, nullptr, nullptr, 0));
+        }
+        return ACX_OK;
+    });
 }
 
 int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* mr, uint32_t slot0, uint32_t count, uint64_t* n_bad) {
-    if (!mr || !n_bad || count == 0 || slot0 + count > kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot0 + count <= 16)");
-    if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "system is held whole on shard 0");
-    acx_mgpu* mg = mr->mg;
-    std::lock_guard<std::mutex> g(mg->mu);
-    DevGuard dg;
-    const uint32_t W = mg->W;
-    std::vector<unsigned long long> host(2 * count), init(2 * count);
-    for (uint32_t i = 0; i < count; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
-    for (uint32_t i = 0; i < count; ++i) n_bad[i] = 0;
-    if (mg->rccl) {
-        // ONE all-reduce for the whole range ({n_bad, first_bad} pairs; the first_bad words are not meaningful after a
-        // sum): into the second half of the ring buffer
-        NCCL_TRY(mg, mg->api->GroupStart());
-        for (uint32_t s = 0; s < W; ++s) {
-            unsigned long long* ring = mr->part[s].ring;
-            const ncclResult_t r = mg->api->AllReduce(ring + 2 * slot0, ring + 2 * kMgRing + 2 * slot0, 2 * count, ncclUint64, ncclSum,
-                                                      mg->sh[s].comm, mg->sh[s].ctx->stream);
-            if (r != ncclSuccess) { (void)mg->api->GroupEnd(); return fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r)); }
+    return guarded([&]() -> int {
+        if (!mr || !n_bad || count == 0 || slot0 + count > kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot0 + count <= 16)");
+        if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "system is held whole on shard 0");
+        acx_mgpu* mg = mr->mg;
+        std::lock_guard<std::mutex> g(mg->mu);
+        DevGuard dg;
+        const uint32_t W = mg->W;
+        std::vector<unsigned long long> host(2 * count), init(2 * count);
+        for (uint32_t i = 0; i < count; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
+        for (uint32_t i = 0; i < count; ++i) n_bad[i] = 0;
+        if (mg->rccl) {
+            // ONE all-reduce for the whole range ({n_bad, first_bad} pairs; the first_bad words are not meaningful after a
+            // sum): into the second half of the ring buffer
+            NCCL_TRY(mg, mg->api->GroupStart());
+            for (uint32_t s = 0; s < W; ++s) {
+                unsigned long long* ring = mr->part[s].ring;
+                const ncclResult_t r = mg->api->AllReduce(ring + 2 * slot0, ring + 2 * kMgRing + 2 * slot0, 2 * count, ncclUint64, ncclSum,
+                                                          mg->sh[s].comm, mg->sh[s].ctx->stream);
+                if (r != ncclSuccess) { (void)mg->api->GroupEnd(); return fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r)); }
+            }
+            NCCL_TRY(mg, mg->api->GroupEnd());
+            for (uint32_t s = 0; s < W; ++s) {
+                MgShard& S = mg->sh[s];
+                HIP_TRY(hipSetDevice(S.device));
+                if (s == 0) HIP_TRY(hipMemcpyAsync(host.data(), mr->part[0].ring + 2 * kMgRing + 2 * slot0, 16 * count, hipMemcpyDeviceToHost, S.ctx->stream));
+                HIP_TRY(hipMemcpyAsync(mr->part[s].ring + 2 * slot0, init.data(), 16 * count, hipMemcpyHostToDevice, S.ctx->stream));
+            }
+            for (uint32_t s = 0; s < W; ++s) {
+                HIP_TRY(hipSetDevice(mg->sh[s].device));
+                HIP_TRY(hipStreamSynchronize(mg->sh[s].ctx->stream));
+            }
+            for (uint32_t i = 0; i < count; ++i) n_bad[i] = host[2 * i];
+            return ACX_OK;
         }
-        NCCL_TRY(mg, mg->api->GroupEnd());
+        std::vector<std::vector<unsigned long long>> per(W, std::vector<unsigned long long>(2 * count));
         for (uint32_t s = 0; s < W; ++s) {
             MgShard& S = mg->sh[s];
             HIP_TRY(hipSetDevice(S.device));
-            if (s == 0) HIP_TRY(hipMemcpyAsync(host.data(), mr->part[0].ring + 2 * kMgRing + 2 * slot0, 16 * count, hipMemcpyDeviceToHost, S.ctx->stream));
+            HIP_TRY(hipMemcpyAsync(per[s].data(), mr->part[s].ring + 2 * slot0, 16 * count, hipMemcpyDeviceToHost, S.ctx->stream));
             HIP_TRY(hipMemcpyAsync(mr->part[s].ring + 2 * slot0, init.data(), 16 * count, hipMemcpyHostToDevice, S.ctx->stream));
         }
         for (uint32_t s = 0; s < W; ++s) {
             HIP_TRY(hipSetDevice(mg->sh[s].device));
             HIP_TRY(hipStreamSynchronize(mg->sh[s].ctx->stream));
+            for (uint32_t i = 0; i < count; ++i) n_bad[i] += per[s][2 * i];
         }
-        for (uint32_t i = 0; i < count; ++i) n_bad[i] = host[2 * i];
         return ACX_OK;
-    }
-    std::vector<std::vector<unsigned long long>> per(W, std::vector<unsigned long long>(2 * count));
-    for (uint32_t s = 0; s < W; ++s) {
-        MgShard& S = mg->sh[s];
-        HIP_TRY(hipSetDevice(S.device));
-        HIP_TRY(hipMemcpyAsync(per[s].data(), mr->part[s].ring + 2 * slot0, 16 * count, hipMemcpyDeviceToHost, S.ctx->stream));
-        HIP_TRY(hipMemcpyAsync(mr->part[s].ring + 2 * slot0, init.data(), 16 * count, hipMemcpyHostToDevice, S.ctx->stream));
-    }
-    for (uint32_t s = 0; s < W; ++s) {
-        HIP_TRY(hipSetDevice(mg->sh[s].device));
-        HIP_TRY(hipStreamSynchronize(mg->sh[s].ctx->stream));
-        for (uint32_t i = 0; i < count; ++i) n_bad[i] += per[s][2 * i];
-    }
-    return ACX_OK;
+    });
 }
 
 // `all (verifyAssignment qap) assignments` (test/Test/Circuit/Arithmetic.hs:209) over all devices in one call: every witness is
@@ -1031,170 +1099,200 @@ int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* mr, uint32_t slot0, uint32_t count, ui
 // witness k+1 crosses PCIe while witness k is being checked), its check accumulates into a ring slot, and the verdicts of up to
 // 16 witnesses are combined by ONE all-reduce.
 int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad) {
-    if (!mr || !ok || (count && !witnesses)) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (count == 0) return ACX_OK;
-    if (!mr->sharded) return acx_r1cs_verify_many(mr->whole, count, witnesses, ok, n_bad, nullptr);
-    acx_mgpu* mg = mr->mg;
-    std::lock_guard<std::mutex> g(mg->mu);
-    DevGuard dg;
-    const uint32_t W = mg->W;
-    mr->witness_resident = false;                   // the resident witness is overwritten
-    mr->h_valid = false;
-    // second witness buffer per shard, allocated on first use
-    std::vector<uint4*> alt(W, nullptr);
-    for (uint32_t s = 0; s < W; ++s) {
-        HIP_TRY(hipSetDevice(mg->sh[s].device));
-        if (hipMalloc((void**)&alt[s], mr->m * 32) != hipSuccess) {
-            for (uint32_t t = 0; t < s; ++t) { (void)hipSetDevice(mg->sh[t].device); (void)hipFree(alt[t]); }
-            return fail(ACX_ERR_OOM, "device allocation failed");
+    return guarded([&]() -> int {
+        if (!mr || !ok || (count && !witnesses)) return fail(ACX_ERR_INVALID_ARG, "null argument");
+        if (count == 0) return ACX_OK;
+        if (!mr->sharded) return acx_r1cs_verify_many(mr->whole, count, witnesses, ok, n_bad, nullptr);
+        acx_mgpu* mg = mr->mg;
+        std::lock_guard<std::mutex> g(mg->mu);
+        DevGuard dg;
+        const uint32_t W = mg->W;
+        mr->witness_resident = false;                   // the resident witness is overwritten
+        mr->h_valid = false;
+        // second witness buffer per shard, allocated on first use
+        std::vector<uint4*> alt(W, nullptr);
+        for (uint32_t s = 0; s < W; ++s) {
+            HIP_TRY(hipSetDevice(mg->sh[s].device));
+            if (hipMalloc((void**)&alt[s], mr->m * 32) != hipSuccess) {
+                for (uint32_t t = 0; t < s; ++t) { (void)hipSetDevice(mg->sh[t].device); (void)hipFree(alt[t]); }
+                return fail(ACX_ERR_OOM, "device allocation failed");
+            }
         }
-    }
-    auto cleanup = [&]() {
-        for (uint32_t s = 0; s < W; ++s) { (void)hipSetDevice(mg->sh[s].device); (void)hipStreamSynchronize(mg->sh[s].ctx->stream); (void)hipFree(alt[s]); }
-    };
-    for (auto& S : mg->sh) {                        // canonicity flag of the whole call
-        HIP_TRY(hipSetDevice(S.device));
-        HIP_TRY(hipMemsetAsync(S.d_res + 2, 0, 4, S.ctx->stream));
-    }
-    int rc = ACX_OK;
-    for (uint64_t done = 0; done < count && rc == ACX_OK; done += kMgRing) {
-        const uint32_t k = (uint32_t)std::min<uint64_t>(kMgRing, count - done);
-        rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
-            MgShard& S = mg->sh[s];
+        auto cleanup = [&]() {
+            for (uint32_t s = 0; s < W; ++s) { (void)hipSetDevice(mg->sh[s].device); (void)hipStreamSynchronize(mg->sh[s].ctx->stream); (void)hipFree(alt[s]); }
+        };
+        for (auto& S : mg->sh) {                        // canonicity flag of the whole call
             HIP_TRY(hipSetDevice(S.device));
-            CtxLock lock(S.ctx->mu);
-            const auto& P = mr->part[s];
-            for (uint32_t i = 0; i < k; ++i) {
-                uint4* d_w = ((done + i) & 1) ? alt[s] : P.d_w;
-                // the stream is in order: the check of witness i-2 (same buffer) precedes this copy
-                HIP_TRY(hipMemcpyAsync(d_w, witnesses + (done + i) * mr->m, mr->m * 32, hipMemcpyHostToDevice, S.ctx->stream));
-                ACX_TRY(launch_convert(S.ctx, true, d_w, d_w, mr->m, (uint32_t*)(S.d_res + 2)));
-                ACX_TRY(launch_residual(P.slab, d_w, P.row0, P.ring + 2 * i, nullptr, nullptr, 0));
+            HIP_TRY(hipMemsetAsync(S.d_res + 2, 0, 4, S.ctx->stream));
+        }
+        int rc = ACX_OK;
+        for (uint64_t done = 0; done < count && rc == ACX_OK; done += kMgRing) {
+            const uint32_t k = (uint32_t)std::min<uint64_t>(kMgRing, count - done);
+            rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+                MgShard& S = mg->sh[s];
+                HIP_TRY(hipSetDevice(S.device));
+                CtxLock lock(S.ctx->mu);
+                const auto& P = mr->part[s];
+                for (uint32_t i = 0; i < k; ++i) {
+                    uint4* d_w = ((done + i) & 1) ? alt[s] : P.d_w;
+                    // the stream is in order: the check of witness i-2 (same buffer) precedes this copy
+                    HIP_TRY(hipMemcpyAsync(d_w, witnesses + (done + i) * mr->m, mr->m * 32, hipMemcpyHostToDevice, S.ctx->stream));
+                    ACX_TRY(launch_convert(S.ctx, true, d_w, d_w, mr->m, (uint32_t*)(S.d_res + 2)));
+                    ACX_TRY(launch_residual(P.slab, d_w, P.row0, P.ring + 2 * i, nullptr, nullptr, 0));
+                }
+                return ACX_OK;
+            });
+            if (rc != ACX_OK) break;
+            // ONE collective for the k verdicts (the body of acx_mgpu_r1cs_verdicts, slots 0 .. k-1)
+            std::vector<unsigned long long> host(2 * k, 0), init(2 * k);
+            for (uint32_t i = 0; i < k; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
+            std::vector<uint64_t> bad(k, 0);
+            if (mg->rccl) {
+                ncclResult_t r = mg->api->GroupStart();
+                for (uint32_t s = 0; s < W && r == ncclSuccess; ++s)
+                    r = mg->api->AllReduce(mr->part[s].ring, mr->part[s].ring + 2 * kMgRing, 2 * k, ncclUint64, ncclSum, mg->sh[s].comm, mg->sh[s].ctx->stream);
+                const ncclResult_t r2 = mg->api->GroupEnd();
+                if (r != ncclSuccess || r2 != ncclSuccess) { rc = fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r != ncclSuccess ? r : r2)); break; }
+                for (uint32_t s = 0; s < W; ++s) {
+                    (void)hipSetDevice(mg->sh[s].device);
+                    if (s == 0) (void)hipMemcpyAsync(host.data(), mr->part[0].ring + 2 * kMgRing, 16 * k, hipMemcpyDeviceToHost, mg->sh[0].ctx->stream);
+                    (void)hipMemcpyAsync(mr->part[s].ring, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
+                }
+                for (uint32_t s = 0; s < W; ++s) { (void)hipSetDevice(mg->sh[s].device); if (hipStreamSynchronize(mg->sh[s].ctx->stream) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream synchronisation failed"); }
+                for (uint32_t i = 0; i < k; ++i) bad[i] = host[2 * i];
+            } else {
+                std::vector<std::vector<unsigned long long>> per(W, std::vector<unsigned long long>(2 * k));
+                for (uint32_t s = 0; s < W; ++s) {
+                    (void)hipSetDevice(mg->sh[s].device);
+                    (void)hipMemcpyAsync(per[s].data(), mr->part[s].ring, 16 * k, hipMemcpyDeviceToHost, mg->sh[s].ctx->stream);
+                    (void)hipMemcpyAsync(mr->part[s].ring, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
+                }
+                for (uint32_t s = 0; s < W; ++s) {
+                    (void)hipSetDevice(mg->sh[s].device);
+                    if (hipStreamSynchronize(mg->sh[s].ctx->stream) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream synchronisation failed");
+                    for (uint32_t i = 0; i < k; ++i) bad[i] += per[s][2 * i];
+                }
             }
-            return ACX_OK;
-        });
-        if (rc != ACX_OK) break;
-        // ONE collective for the k verdicts (the body of acx_mgpu_r1cs_verdicts, slots 0 .. k-1)
-        std::vector<unsigned long long> host(2 * k, 0), init(2 * k);
-        for (uint32_t i = 0; i < k; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
-        std::vector<uint64_t> bad(k, 0);
-        if (mg->rccl) {
-            ncclResult_t r = mg->api->GroupStart();
-            for (uint32_t s = 0; s < W && r == ncclSuccess; ++s)
-                r = mg->api->AllReduce(mr->part[s].ring, mr->part[s].ring + 2 * kMgRing, 2 * k, ncclUint64, ncclSum, mg->sh[s].comm, mg->sh[s].ctx->stream);
-            const ncclResult_t r2 = mg->api->GroupEnd();
-            if (r != ncclSuccess || r2 != ncclSuccess) { rc = fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r != ncclSuccess ? r : r2)); break; }
-            for (uint32_t s = 0; s < W; ++s) {
-                (void)hipSetDevice(mg->sh[s].device);
-                if (s == 0) (void)hipMemcpyAsync(host.data(), mr->part[0].ring + 2 * kMgRing, 16 * k, hipMemcpyDeviceToHost, mg->sh[0].ctx->stream);
-                (void)hipMemcpyAsync(mr->part[s].ring, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
-            }
-            for (uint32_t s = 0; s < W; ++s) { (void)hipSetDevice(mg->sh[s].device); if (hipStreamSynchronize(mg->sh[s].ctx->stream) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream synchronisation failed"); }
-            for (uint32_t i = 0; i < k; ++i) bad[i] = host[2 * i];
-        } else {
-            std::vector<std::vector<unsigned long long>> per(W, std::vector<unsigned long long>(2 * k));
-            for (uint32_t s = 0; s < W; ++s) {
-                (void)hipSetDevice(mg->sh[s].device);
-                (void)hipMemcpyAsync(per[s].data(), mr->part[s].ring, 16 * k, hipMemcpyDeviceToHost, mg->sh[s].ctx->stream);
-                (void)hipMemcpyAsync(mr->part[s].ring, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
-            }
-            for (uint32_t s = 0; s < W; ++s) {
-                (void)hipSetDevice(mg->sh[s].device);
-                if (hipStreamSynchronize(mg->sh[s].ctx->stream) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream synchronisation failed");
-                for (uint32_t i = 0; i < k; ++i) bad[i] += per[s][2 * i];
+            for (uint32_t i = 0; i < k && rc == ACX_OK; ++i) {
+                ok[done + i] = bad[i] == 0;
+                if (n_bad) n_bad[done + i] = bad[i];
             }
         }
-        for (uint32_t i = 0; i < k && rc == ACX_OK; ++i) {
-            ok[done + i] = bad[i] == 0;
-            if (n_bad) n_bad[done + i] = bad[i];
+        if (rc == ACX_OK) {
+            uint32_t flag = 0;
+            (void)hipSetDevice(mg->sh[0].device);
+            if (hipMemcpy(&flag, mg->sh[0].d_res + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ACX_ERR_HIP, "flag fetch failed");
+            else if (flag) rc = fail(ACX_ERR_NONCANONICAL, "element >= p");
         }
-    }
-    if (rc == ACX_OK) {
-        uint32_t flag = 0;
-        (void)hipSetDevice(mg->sh[0].device);
-        if (hipMemcpy(&flag, mg->sh[0].d_res + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ACX_ERR_HIP, "flag fetch failed");
-        else if (flag) rc = fail(ACX_ERR_NONCANONICAL, "element >= p");
-    }
-    cleanup();
-    return rc;
+        cleanup();
+        return rc;
+    });
 }
 
 int acx_mgpu_qap_h_resident(acx_mgpu_r1cs* mr, const acx_fr* delta, int* ok) {
-    if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
-    H256 dl[3];
-    if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], mr->mg->sh[0].ctx->hf, dl[k]));
-    std::lock_guard<std::mutex> g(mr->mg->mu);
-    DevGuard dg;
-    bool good = false;
-    ACX_TRY(mg_qap_h_resident(mr, delta ? dl : nullptr, &good));
-    *ok = good;
-    return ACX_OK;
+    return guarded([&]() -> int {
+        if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
+        if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
+        H256 dl[3];
+        if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], mr->mg->sh[0].ctx->hf, dl[k]));
+        std::lock_guard<std::mutex> g(mr->mg->mu);
+        DevGuard dg;
+        bool good = false;
+        ACX_TRY(mg_qap_h_resident(mr, delta ? dl : nullptr, &good));
+        *ok = good;
+        return ACX_OK;
+    });
 }
 
 int acx_mgpu_qap_h_fetch(acx_mgpu_r1cs* mr, acx_fr* out_h, uint64_t* h_len) {
-    if (!mr || !out_h || !h_len) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (!mr->sharded || !mr->h_valid) return fail(ACX_ERR_UNSUPPORTED, "no h(x) on the devices (acx_mgpu_qap_h_resident)");
-    acx_mgpu* mg = mr->mg;
-    std::lock_guard<std::mutex> g(mg->mu);
-    DevGuard dg;
-    const uint64_t N = 1ull << mr->log_n, L = N / mg->W, R = 1ull << mr->log_r, C = N / R;
-    ACX_TRY(mg_ensure_io(mg, L));
-    std::vector<uint4*> hp(mg->W);
-    for (uint32_t s = 0; s < mg->W; ++s) hp[s] = mr->part[s].vec + 2 * 7 * L;
-    ACX_TRY(mg_fetch_natural(mg, hp.data(), R, C / mg->W, C, out_h));                         // COLS ownership
-    write_h256(&out_h[N], mg->sh[0].ctx->hf, mr->h_top);
-    uint64_t len = N + 1;
-    static const uint8_t zero32[32] = {0};
-    while (len > 0 && std::memcmp(out_h[len - 1].b, zero32, 32) == 0) --len;
-    *h_len = len;
-    return ACX_OK;
+    return guarded([&]() -> int {
+        if (!mr || !out_h || !h_len) return fail(ACX_ERR_INVALID_ARG, "null argument");
+        if (!mr->sharded || !mr->h_valid) return fail(ACX_ERR_UNSUPPORTED, "no h(x) on the devices (acx_mgpu_qap_h_resident)");
+        acx_mgpu* mg = mr->mg;
+        std::lock_guard<std::mutex> g(mg->mu);
+        DevGuard dg;
+        const uint64_t N = 1ull << mr->log_n, L = N / mg->W, R = 1ull << mr->log_r, C = N / R;
+        ACX_TRY(mg_ensure_io(mg, L));
+        std::vector<uint4*> hp(mg->W);
+        for (uint32_t s = 0; s < mg->W; ++s) hp[s] = mr->part[s].vec + 2 * 7 * L;
+        ACX_TRY(mg_fetch_natural(mg, hp.data(), R, C / mg->W, C, out_h));                         // COLS ownership
+        write_h256(&out_h[N], mg->sh[0].ctx->hf, mr->h_top);
+        uint64_t len = N + 1;
+        static const uint8_t zero32[32] = {0};
+        while (len > 0 && std::memcmp(out_h[len - 1].b, zero32, 32) == 0) --len;
+        *h_len = len;
+        return ACX_OK;
+    });
 }
 
 int acx_mgpu_qap_h(acx_mgpu_r1cs* mr, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok) {
-    if (!mr || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (!mr->sharded) return acx_qap_h(mr->whole, witness, delta, out_h, h_len, ok);
-    H256 dl[3];
-    if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], mr->mg->sh[0].ctx->hf, dl[k]));
-    {
-        std::lock_guard<std::mutex> g(mr->mg->mu);
+    return guarded([&]() -> int {
+        if (!mr || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
+        if (!mr->sharded) return acx_qap_h(mr->whole, witness, delta, out_h, h_len, ok);
+        H256 dl[3];
+        if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], mr->mg->sh[0].ctx->hf, dl[k]));
+        {
+            std::lock_guard<std::mutex> g(mr->mg->mu);
+            DevGuard dg;
+            ACX_TRY(mg_upload_witness(mr, witness));
+            bool good = false;
+            const int rc = mg_qap_h_resident(mr, delta ? dl : nullptr, &good);
+            if (rc != ACX_OK) { if (rc == ACX_ERR_NONCANONICAL) mr->witness_resident = false; return rc; }
+            *ok = good;
+        }
+        return acx_mgpu_qap_h_fetch(mr, out_h, h_len);
+    });
+}
+
+int acx_mgpu_qap_columns(acx_mgpu_r1cs* mr, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out, uint64_t* out_len) {
+    if (!mr || matrix < 0 || matrix > 2 || !out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    if (wire_begin > mr->m || wire_count > mr->m - wire_begin) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
+    if (wire_count == 0) return ACX_OK;
+    if (!mr->sharded) return acx_qap_columns(mr->whole, matrix, wire_begin, wire_count, out, out_len);
+    return guarded([&]() -> int {
+        acx_mgpu* mg = mr->mg;
+        std::lock_guard<std::mutex> g(mg->mu);
         DevGuard dg;
-        ACX_TRY(mg_upload_witness(mr, witness));
-        bool good = false;
-        const int rc = mg_qap_h_resident(mr, delta ? dl : nullptr, &good);
-        if (rc != ACX_OK) { if (rc == ACX_ERR_NONCANONICAL) mr->witness_resident = false; return rc; }
-        *ok = good;
-    }
-    return acx_mgpu_qap_h_fetch(mr, out_h, h_len);
+        ACX_TRY(mg_ensure_replicas(mr));
+        // contiguous wire ranges of equal size, one per shard, straight into the caller's buffers: no exchange at all
+        const uint64_t N = 1ull << mr->log_n, W = mg->W;
+        return mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+            const uint64_t w0 = wire_count * s / W, w1 = wire_count * (s + 1) / W;
+            if (w0 == w1) return ACX_OK;
+            return acx_qap_columns(mr->part[s].full, matrix, wire_begin + w0, w1 - w0, out + w0 * N, out_len ? out_len + w0 : nullptr);
+        });
+    });
 }
 
 int acx_mgpu_ntt(acx_mgpu* mg, uint32_t log_n, int inverse, const acx_fr* shift, const acx_fr* in, acx_fr* out) {
-    if (!mg || !in || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
-    if (!mg_can_distribute(mg->W, log_n)) return acx_ntt(mg->sh[0].ctx, log_n, 1, inverse, shift, in, out);
-    const HostField& hf = mg->sh[0].ctx->hf;
-    if ((int)log_n > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
-    H256 sh;
-    if (shift) {
-        ACX_TRY(read_h256(shift, hf, sh));
-        if (sh.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift must be nonzero");
-    }
-    std::lock_guard<std::mutex> g(mg->mu);
-    DevGuard dg;
-    const uint32_t W = mg->W, log_r = log_n / 2;
-    const uint64_t N = 1ull << log_n, L = N / W, R = 1ull << log_r, C = N / R;
-    ACX_TRY(mg_ensure_slots(mg, L));
-    ACX_TRY(mg_ensure_io(mg, L));
-    // blocks: input in slot 1's send buffer, output in slot 1's recv buffer (slot 0 carries the transform)
-    std::vector<uint4*> src(W), dst(W);
-    for (uint32_t s = 0; s < W; ++s) { src[s] = mg->sh[s].slot[1].send; dst[s] = mg->sh[s].slot[1].recv; }
-    // forward: COLS -> ROWS; inverse: ROWS -> COLS
-    if (!inverse) ACX_TRY(mg_push_natural(mg, in, R, C / W, C, src.data())); else ACX_TRY(mg_push_natural(mg, in, C, R / W, R, src.data()));
-    ACX_TRY(mg_check_canonical(mg));
-    MgNtt nt(mg, log_n, log_r);
-    ACX_TRY(nt.begin(0, src.data(), inverse, shift ? &sh : nullptr));
-    ACX_TRY(nt.finish(0, dst.data(), inverse, shift ? &sh : nullptr));
-    if (!inverse) return mg_fetch_natural(mg, dst.data(), C, R / W, R, out);
-    return mg_fetch_natural(mg, dst.data(), R, C / W, C, out);
+    return guarded([&]() -> int {
+        if (!mg || !in || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
+        if (!mg_can_distribute(mg->W, log_n)) return acx_ntt(mg->sh[0].ctx, log_n, 1, inverse, shift, in, out);
+        const HostField& hf = mg->sh[0].ctx->hf;
+        if ((int)log_n > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
+        H256 sh;
+        if (shift) {
+            ACX_TRY(read_h256(shift, hf, sh));
+            if (sh.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift must be nonzero");
+        }
+        std::lock_guard<std::mutex> g(mg->mu);
+        DevGuard dg;
+        const uint32_t W = mg->W, log_r = log_n / 2;
+        const uint64_t N = 1ull << log_n, L = N / W, R = 1ull << log_r, C = N / R;
+        ACX_TRY(mg_ensure_slots(mg, L));
+        ACX_TRY(mg_ensure_io(mg, L));
+        // blocks: input in slot 1's send buffer, output in slot 1's recv buffer (slot 0 carries the transform)
+        std::vector<uint4*> src(W), dst(W);
+        for (uint32_t s = 0; s < W; ++s) { src[s] = mg->sh[s].slot[1].send; dst[s] = mg->sh[s].slot[1].recv; }
+        // forward: COLS -> ROWS; inverse: ROWS -> COLS
+        if (!inverse) ACX_TRY(mg_push_natural(mg, in, R, C / W, C, src.data())); else ACX_TRY(mg_push_natural(mg, in, C, R / W, R, src.data()));
+        ACX_TRY(mg_check_canonical(mg));
+        MgNtt nt(mg, log_n, log_r);
+        ACX_TRY(nt.begin(0, src.data(), inverse, shift ? &sh : nullptr));
+        ACX_TRY(nt.finish(0, dst.data(), inverse, shift ? &sh : nullptr));
+        if (!inverse) return mg_fetch_natural(mg, dst.data(), C, R / W, R, out);
+        return mg_fetch_natural(mg, dst.data(), R, C / W, C, out);
+    });
 }
 
 }  // extern "C"

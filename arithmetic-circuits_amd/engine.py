@@ -496,6 +496,14 @@ class MgR1CS:
         check(self.mg.lib.acx_mgpu_r1cs_verify(self._h, _ptr(w), C.byref(ok), C.byref(nbad), C.byref(first) if want_first else None))
         return bool(ok.value), nbad.value, first.value
 
+    def qap_columns(self, matrix: int, wire_begin: int, wire_count: int) -> Tuple[np.ndarray, np.ndarray]:
+        """createPolynomialsFFT for a wire range of one matrix, the wires shared out over the devices (no exchange)."""
+        N = 1 << self.log_n
+        out = np.zeros((wire_count, N, 4), dtype=np.uint64)
+        lens = np.zeros(wire_count, dtype=np.uint64)
+        check(self.mg.lib.acx_mgpu_qap_columns(self._h, matrix, wire_begin, wire_count, _ptr(out), _ptr(lens)))
+        return out, lens
+
     def verify_many(self, witnesses: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """`all (verifyAssignment qap) assignments` in one call: witnesses (count, m, 4) canonical -> (ok[count] bool, n_bad[count])."""
         w = np.ascontiguousarray(witnesses, dtype=np.uint64)

@@ -120,6 +120,15 @@ def cyclic_rows(log_n: int, log_r: int, world: int, rank: int, ascending: bool =
     return (rows.T if ascending else rows).reshape(-1)
 
 
+def wire_range(wire_begin: int, wire_count: int, world: int, rank: int) -> Tuple[int, int]:
+    """Per-wire polynomials (`createPolynomialsFFT`, src/QAP.hs:512-525) shard by WIRE with no communication:
+    rank's contiguous part (first wire, count) of a wire range, the split acx_mgpu_qap_columns uses inside one process.  A
+    one-process-per-GPU host loads the whole system on every rank (a column's interpolation needs every row) and calls
+    R1CS.qap_columns(matrix, *wire_range(...)) on its own part; the parts tile the range in rank order."""
+    w0, w1 = wire_count * rank // world, wire_count * (rank + 1) // world
+    return wire_begin + w0, w1 - w0
+
+
 RowSource = Callable[[np.ndarray], Tuple[tuple, tuple, tuple]]
 
 

@@ -93,6 +93,18 @@ int main(int argc, char** argv) {
     CHECK(acx_qap_h(r, w, NULL, h1, &h1_len, &ok1));
     if (!ok1 || h1_len != h_len || memcmp(h, h1, h_len * 32) != 0) { fprintf(stderr, "h(x) differs from the single-GPU result\n"); return 1; }
 
+    /* createPolynomialsFFT for 24 wires of A: the wires shared out over the devices, no exchange */
+    {
+        const uint64_t wires = 24, wb = 1 + K / 2;
+        acx_fr* cols = malloc(wires * N * 32);
+        acx_fr* cols1 = malloc(wires * N * 32);
+        uint64_t lens[24], lens1[24];
+        CHECK(acx_mgpu_qap_columns(mr, 0, wb, wires, cols, lens));
+        CHECK(acx_qap_columns(r, 0, wb, wires, cols1, lens1));
+        if (memcmp(cols, cols1, wires * N * 32) != 0 || memcmp(lens, lens1, sizeof lens) != 0) { fprintf(stderr, "QAP columns differ from the single-GPU result\n"); return 1; }
+        free(cols); free(cols1);
+    }
+
     /* a corrupted assignment: same count, same first violated row, Nothing */
     const uint64_t victim = 1 + K + n / 3;
     w[victim].b[0] ^= 1;

@@ -385,6 +385,12 @@ int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* r, const acx_fr* witness, int* ok, uint6
 int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* r, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad);
 /* `verificationWitnessZk` (src/QAP.hs:300-327) over all devices: arguments and results of acx_qap_h (out_h holds N + 1 elements). */
 int acx_mgpu_qap_h(acx_mgpu_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok);
+/* `createPolynomialsFFT primRoots genQap` (src/QAP.hs:512-525) for a wire range of one matrix, the wires shared out over
+ * the devices (columns are independent: no exchange at all): arguments and results of acx_qap_columns, every
+ * device writing its wires' coefficients straight into `out`.  A column's interpolation needs every row of its matrix, so
+ * the FIRST call gives every device a copy of the whole system (read back from the row slabs; kept until
+ * acx_mgpu_r1cs_destroy) -- callers that only verify or compute h(x) never pay for it. */
+int acx_mgpu_qap_columns(acx_mgpu_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out, uint64_t* out_len);
 /* `FFT.fft` / `FFT.interpolate` (galois-fft; src/QAP.hs:521-524) of ONE 2^log_n-point vector spread over the devices: host data
  * in natural order in and out, arguments of acx_ntt with batch = 1. */
 int acx_mgpu_ntt(acx_mgpu* mg, uint32_t log_n, int inverse, const acx_fr* shift, const acx_fr* in, acx_fr* out);

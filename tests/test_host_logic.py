@@ -291,3 +291,19 @@ def test_threaded_row_generation_equals_sequential(acx, monkeypatch):
     lib = acx._lib.load()
     assert lib.acx_circuit_create(0, C.byref(gl), C.byref(h)) == 0
     lib.acx_circuit_destroy(h)
+
+
+def test_wire_ranges_tile_the_requested_range(acx):
+    """The per-wire split of createPolynomialsFFT over ranks / shards (no communication): contiguous parts in
+    rank order that tile the range exactly, sizes differing by at most one, also with fewer wires than ranks."""
+    par = acx.parallel
+    for begin, count in ((0, 64), (17, 37), (5, 3), (9, 1), (0, 0), (123, 1000003)):
+        for world in (1, 2, 4, 8):
+            parts = [par.wire_range(begin, count, world, r) for r in range(world)]
+            at = begin
+            for w0, c in parts:
+                assert w0 == at and c >= 0
+                at += c
+            assert at == begin + count
+            sizes = [c for _, c in parts]
+            assert max(sizes) - min(sizes) <= 1

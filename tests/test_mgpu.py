@@ -294,3 +294,64 @@ def test_mgpu_calls_from_several_threads(acx, request, devices):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0, 0], [0] * 8], ids=lambda d: f"W{len(d)}")
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+def test_mgpu_qap_columns_shared_out_by_wire(acx, request, field, devices):
+    """createPolynomialsFFT (/root/reference/src/QAP.hs:512-525) behind the multi-GPU handle: wires shared out over the
+    shards, every shard interpolating its wires on its own copy of the whole system (built on the first call from the
+    row slabs) -- bit-equal to the C oracle and to acx_qap_columns of one GPU, coefficients and stripped lengths, for
+    ranges that divide evenly, ragged ones, fewer wires than shards, and the gate mix whose Split rows are long."""
+    synth = acx.synth
+    mg = _mg(acx, request, field, devices)
+    mg.set_shard_threshold(10)
+    orc = _orc(request, field)
+    ctx1 = request.getfixturevalue("ctx_bn254" if field == "bn254" else "ctx_bls")
+    n = (1 << 12) - 19
+    s = synth.mulgraph(n, n_in=48, window=300, seed=0xC01 + len(devices), field=field)
+    mats = s.rows()
+    mr = mg.from_circuit(s.circuit)
+    r1 = s.circuit.to_r1cs(ctx1)
+    assert mr.n_shards == len(devices)
+    for k, w0, cnt in ((0, 0, 64), (1, 17, 37), (2, mr.m - 5, 5), (0, 3, 3), (1, 200, 1)):
+        cols, lens = mr.qap_columns(k, w0, cnt)
+        want = orc.qap_columns(n, mr.log_n, mats[k], w0, cnt, nthreads=8)
+        one, one_lens = r1.qap_columns(k, w0, cnt)
+        assert np.array_equal(cols, want) and np.array_equal(cols, one)
+        assert np.array_equal(lens, one_lens)
+    # verification and the quotient still work after the copies exist (they are separate handles on the same contexts)
+    w = s.witness()
+    assert mr.verify(w) == (True, 0, U64_MAX)
+    h, ok = mr.qap_h(w)
+    h1, ok1 = r1.qap_h(w)
+    assert ok and ok1 and np.array_equal(h, h1)
+    with pytest.raises(acx.AcxError):
+        mr.qap_columns(0, mr.m - 2, 3)
+    with pytest.raises(acx.AcxError):
+        mr.qap_columns(3, 0, 1)
+
+
+def test_mgpu_qap_columns_gate_mix_and_small_system(acx, request):
+    """The reference's gate mix (long Split rows) through the per-wire path on two shards, and a system below the shard
+    threshold (held whole on the first device: same call, same answer)."""
+    import random
+    from tests import helpers as H
+    synth = acx.synth
+    mg = _mg(acx, request, "bn254", [0, 0])
+    mg.set_shard_threshold(10)
+    orc = _orc(request, "bn254")
+    rnd = random.Random(777)
+    gates = H.arb_arith_circuit(rnd, R.BN254.p, 4, 200, dist=(50, 10, 2))
+    host = H.to_acx_circuit(acx, gates).marshal("bn254")
+    mats = host.rows()
+    mr = mg.from_circuit(host)
+    assert mr.n_shards == 2
+    for k in range(3):
+        cols, lens = mr.qap_columns(k, 1, 40)
+        assert np.array_equal(cols, orc.qap_columns(mr.n, mr.log_n, mats[k], 1, 40, nthreads=8))
+    small = synth.mulgraph(300, n_in=8, window=64, seed=5, field="bn254")
+    ms = mg.from_circuit(small.circuit)
+    assert ms.n_shards == 1
+    cols, _ = ms.qap_columns(0, 0, 16)
+    assert np.array_equal(cols, orc.qap_columns(300, ms.log_n, small.rows()[0], 0, 16, nthreads=4))
