@@ -416,3 +416,62 @@ int orc_qap_h(const orc_field *F, uint64_t n, uint64_t m, int log_n,
     free(L0); free(R0); for (int k = 0; k < 3; ++k) free(d[k]);
     return 0;
 }
+
+/* ------------------------------------------------------------------ the reference's OWN algorithm (baseline timing)
+ * verifyAssignment / verificationWitness as src/QAP.hs:276-327 computes them -- in the POLYNOMIAL domain, on the dense
+ * per-wire polynomials createPolynomialsFFT produces (src/QAP.hs:512-525), single threaded like the reference:
+ *     L = sum_k w_k * A_k(x),  R, O alike      foldQapSet . combineWithDefaults (src/QAP.hs:163-181,226-230,314-323):
+ *                                               one scalar x polynomial product and one polynomial sum per wire
+ *     P = L * R - O                             dense polynomial product (poly's VPoly)
+ *     (q, r) = P `quotRem` T,  T = x^N - 1      long division over the DENSE coefficient vector of T (src/QAP.hs:324-327)
+ *     Just q  iff  r == 0
+ * cols: 3 x m x N canonical coefficients (matrix, wire, coefficient: three orc_qap_columns outputs back to back),
+ * witness: m canonical.  out_q: N canonical coefficients of the quotient or NULL.  *ok = (r == 0).
+ * BASELINE.md section 2 "reference-algorithm mode": what the Haskell ALGORITHM costs on configs[0]; a C restatement, not
+ * GHC.  The product of a canonical and a Montgomery operand is canonical, so nothing is converted per coefficient. */
+int orc_ref_verify(const orc_field *F, uint64_t m, int log_n, const uint64_t *cols, const uint64_t *witness,
+                   uint64_t *out_q, int *ok) {
+    size_t N = (size_t)1 << log_n;
+    fe *wm = witness_to_mont(F, witness, m);
+    fe *S[3];
+    for (int k = 0; k < 3; ++k) {
+        S[k] = calloc(N, sizeof(fe));
+        for (uint64_t j = 0; j < m; ++j) {
+            const uint64_t *col = cols + 4 * (((size_t)k * m + j) * N);
+            for (size_t i = 0; i < N; ++i) {
+                fe c, t; memcpy(&c, col + 4 * i, 32);
+                fe_mul(F, &t, &c, &wm[j]);               /* canonical x Montgomery = canonical */
+                fe_add(F, &S[k][i], &S[k][i], &t);
+            }
+        }
+    }
+    /* P = L * R - O, 2N - 1 coefficients (+ one zero so that the division below can address P[2N - 1]) */
+    fe *P = calloc(2 * N, sizeof(fe)), *Lm = malloc(sizeof(fe) * N);
+    for (size_t i = 0; i < N; ++i) fe_to_mont(F, &Lm[i], &S[0][i]);
+    for (size_t i = 0; i < N; ++i)
+        for (size_t j = 0; j < N; ++j) {
+            fe t; fe_mul(F, &t, &Lm[i], &S[1][j]);
+            fe_add(F, &P[i + j], &P[i + j], &t);
+        }
+    for (size_t i = 0; i < N; ++i) fe_sub(F, &P[i], &P[i], &S[2][i]);
+    /* long division by the dense T = (-1, 0, ..., 0, 1): quotient coefficient i - N = leading coefficient, then
+     * P -= q * x^(i-N) * T over all N + 1 coefficients of T, zeros included (a dense-vector quotRem does not skip them) */
+    fe *T = calloc(N + 1, sizeof(fe)), *Q = calloc(N, sizeof(fe));
+    fe one_c = {{1, 0, 0, 0}}, zero = {{0, 0, 0, 0}};
+    T[N] = one_c; fe_sub(F, &T[0], &zero, &one_c);
+    for (size_t i = 2 * N - 1; i >= N; --i) {
+        fe q = P[i], qm; Q[i - N] = q;
+        fe_to_mont(F, &qm, &q);
+        for (size_t j = 0; j <= N; ++j) {
+            fe t; fe_mul(F, &t, &qm, &T[j]);
+            fe_sub(F, &P[i - N + j], &P[i - N + j], &t);
+        }
+    }
+    int zero_rem = 1;
+    for (size_t i = 0; i < N; ++i) if (!fe_is_zero(&P[i])) { zero_rem = 0; break; }
+    *ok = zero_rem;
+    if (out_q) memcpy(out_q, Q, N * 32);
+    free(wm); free(P); free(Lm); free(T); free(Q);
+    for (int k = 0; k < 3; ++k) free(S[k]);
+    return 0;
+}

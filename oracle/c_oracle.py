@@ -127,6 +127,21 @@ class COracle:
             raise ValueError("orc_qap_columns failed")
         return out
 
+    def ref_verify(self, m: int, log_n: int, cols: np.ndarray, witness: np.ndarray) -> Tuple[np.ndarray, bool]:
+        """The reference's own polynomial-domain verificationWitness (dense per-wire polynomials, dense product, long
+        division; orc_ref_verify): cols = (3, m, N, 4) canonical coefficients -> (quotient N coefficients, remainder == 0)."""
+        N = 1 << log_n
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        assert cols.shape == (3, m, N, 4)
+        w = np.ascontiguousarray(witness, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((N, 4), dtype=np.uint64)
+        ok = C.c_int(0)
+        rc = self.lib.orc_ref_verify(self._F, C.c_uint64(m), C.c_int(log_n), _p(cols, C.c_uint64), _p(w, C.c_uint64),
+                                     _p(out, C.c_uint64), C.byref(ok))
+        if rc:
+            raise ValueError("orc_ref_verify failed")
+        return out, bool(ok.value)
+
     def qap_h(self, n: int, m: int, log_n: int, A, B, Cm, witness: np.ndarray, delta: Optional[Sequence[int]] = None,
               nthreads: int = 1) -> Tuple[np.ndarray, bool]:
         keep, args = [], []

@@ -118,3 +118,36 @@ def test_ntt_threads_equal_single():
     b = orc.ntt(xs, 13, nthreads=4)
     assert np.array_equal(a, b)
     assert np.array_equal(orc.ntt(a, 13, inverse=True, nthreads=3), xs)
+
+
+@pytest.mark.parametrize("fname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("seed", range(3))
+def test_reference_algorithm_mode_equals_literal_oracle(fname, seed):
+    """orc_ref_verify -- the C restatement of the reference's OWN polynomial-domain algorithm (dense per-wire polynomials,
+    scalar x polynomial sums, dense product, long division by x^N - 1: /root/reference/src/QAP.hs:276-327), which bench.py
+    times on configs[0] as `cpu_baseline.reference_algorithm` -- against the literal big-int oracle: same Bool, same
+    quotient, valid and corrupted assignments; and against the evaluation-domain h(x) of the same file."""
+    field = R.BN254 if fname == "bn254" else R.BLS12_381
+    p = field.p
+    orc = COracle(fname)
+    rnd = random.Random(7100 + seed)
+    gates, num_vars, gen, dims, n, m, mats = _case(rnd, field, rnd.randrange(3, 10))
+    qap = R.create_polynomials_fft(field.root_of_unity, gen, p)
+    log_n = max(0, (n - 1).bit_length())
+    cols = np.stack([orc.qap_columns(n, log_n, mats[k], 0, m) for k in range(3)])
+    for trial in range(4):
+        a = R.generate_assignment(gates, H.arb_input_vector(rnd, p, num_vars), p)
+        w = H.qapset_to_flat(a, dims, p)
+        if trial >= 2:
+            k = rnd.randrange(1, m)
+            w[k] = (w[k] + 1 + rnd.randrange(p - 1)) % p
+            base = [1, 1 + dims[0], 1 + dims[0] + dims[1]]
+            kind = 2 if k >= base[2] else (1 if k >= base[1] else 0)
+            (a.inputs, a.intermediates, a.outputs)[kind][k - base[kind]] = w[k]
+        want_h = R.verification_witness(qap, a, p)
+        q, ok = orc.ref_verify(m, log_n, cols, ints_to_limbs(w))
+        assert ok == (want_h is not None)
+        if ok:
+            assert R.to_poly(limbs_to_ints(q), p) == want_h
+            h, ok2 = orc.qap_h(n, m, log_n, *mats, ints_to_limbs(w))
+            assert ok2 and np.array_equal(h[: q.shape[0]], q) and not h[q.shape[0]:].any()
