@@ -154,6 +154,7 @@ struct acx_mgpu_r1cs {
     };
     std::vector<Part> part;
     bool has_cyclic = false;
+    bool verify_only = false;                       // loaded with ACX_MGPU_VERIFY_ONLY: h(x) is refused, not computed some other way
     bool witness_resident = false;
     bool h_valid = false;                           // part[].vec holds h of the resident witness (acx_mgpu_qap_h_fetch)
     H256 h_top{{0, 0, 0, 0}};                       // coefficient N of the zero-knowledge quotient (d1 d2), Montgomery
@@ -609,7 +610,8 @@ int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], 
         *out = mr.release();
         return ACX_OK;
     }
-    mr->has_cyclic = can_h && !(flags & ACX_MGPU_VERIFY_ONLY);
+    mr->verify_only = (flags & ACX_MGPU_VERIFY_ONLY) != 0;
+    mr->has_cyclic = can_h && !mr->verify_only;
     mr->log_r = log_n / 2;
     mr->part.resize(W);
     const uint64_t L = (1ull << log_n) / W;
@@ -659,10 +661,13 @@ int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], 
 // column's interpolation needs every row of its matrix, so each shard takes a copy of the whole system.  Only callers
 // of acx_mgpu_qap_columns pay for that, on their first call: the slabs are read back from the devices (canonical CSR,
 // acx_r1cs_export), joined on the host and loaded on every shard by one thread each.
-int mg_ensure_replicas(acx_mgpu_r1cs* mr) {
+int mg_ensure_replicas(acx_mgpu_r1cs* mr, bool every_shard = true) {
     acx_mgpu* mg = mr->mg;
     const uint32_t W = mg->W;
-    if (!mr->sharded || mr->part[0].full) return ACX_OK;
+    if (!mr->sharded) return ACX_OK;
+    bool missing = false;
+    for (uint32_t s = 0; s < (every_shard ? W : 1u); ++s) missing = missing || !mr->part[s].full;
+    if (!missing) return ACX_OK;
     const uint64_t n = mr->n;
     std::vector<uint64_t> nnz0[3];                  // entry offset of every slab in the joined matrix
     for (int k = 0; k < 3; ++k) nnz0[k].assign(W + 1, 0);
@@ -697,14 +702,11 @@ int mg_ensure_replicas(acx_mgpu_r1cs* mr) {
         views[k] = acx_csr{rowptr[k].data(), col[k].data(), val[k].data()};
         mp[k] = &views[k];
     }
-    const int rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+    return mg_per_shard_threads(mg, [&](uint32_t s) -> int {          // a shard that fails keeps no copy; the others keep theirs
+        if (mr->part[s].full || (!every_shard && s != 0)) return ACX_OK;
         HIP_TRY(hipSetDevice(mg->sh[s].device));
         return r1cs_from_host(mg->sh[s].ctx, n, mr->m, mp, &mr->part[s].full);
     });
-    if (rc != ACX_OK)
-        for (auto& P : mr->part)
-            if (P.full) { acx_r1cs_destroy(P.full); P.full = nullptr; }
-    return rc;
 }
 
 // verificationWitnessZk over the shards on the resident witness; h stays on the devices in COLS ownership
@@ -713,7 +715,7 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
     const uint32_t W = mg->W;
     const HostField& hf = mg->sh[0].ctx->hf;
     if (!mr->has_cyclic)
-        return fail(ACX_ERR_UNSUPPORTED, "no block-cyclic copy of this system: loaded with ACX_MGPU_VERIFY_ONLY, or N outside 2^10 .. 2^24 / 2 W > sqrt(N)");
+        return fail(ACX_ERR_UNSUPPORTED, "no block-cyclic copy of this system: loaded with ACX_MGPU_VERIFY_ONLY, or N outside 2^10 .. 2^24 / 2 W > sqrt(N) (acx_mgpu_qap_h then answers from one device)");
     if ((int)mr->log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
     const uint64_t N = 1ull << mr->log_n, L = N / W;
     ACX_TRY(mg_ensure_slots(mg, L));
@@ -1229,6 +1231,19 @@ int acx_mgpu_qap_h(acx_mgpu_r1cs* mr, const acx_fr* witness, const acx_fr* delta
     return guarded([&]() -> int {
         if (!mr || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (!mr->sharded) return acx_qap_h(mr->whole, witness, delta, out_h, h_len, ok);
+        if (!mr->has_cyclic && !mr->verify_only) {
+            // a transform size the distributed four-step form does not cover (N above 2^24, or fewer than 2 W points per
+            // digit): the answer still comes, from ONE device on its copy of the whole system (the copies of
+            // acx_mgpu_qap_columns) -- the handle is total over everything the single-GPU call accepts
+            acx_r1cs* full = nullptr;
+            {
+                std::lock_guard<std::mutex> g(mr->mg->mu);
+                DevGuard dg;
+                ACX_TRY(mg_ensure_replicas(mr, false));
+                full = mr->part[0].full;
+            }
+            return acx_qap_h(full, witness, delta, out_h, h_len, ok);
+        }
         H256 dl[3];
         if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], mr->mg->sh[0].ctx->hf, dl[k]));
         {

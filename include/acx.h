@@ -383,7 +383,10 @@ int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* r, const acx_fr* witness, int* ok, uint6
  * while witness k is checked; the verdicts of up to 16 witnesses share one all-reduce.  Any non-canonical element fails the
  * whole call with ACX_ERR_NONCANONICAL. */
 int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* r, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad);
-/* `verificationWitnessZk` (src/QAP.hs:300-327) over all devices: arguments and results of acx_qap_h (out_h holds N + 1 elements). */
+/* `verificationWitnessZk` (src/QAP.hs:300-327) over all devices: arguments and results of acx_qap_h (out_h holds N + 1 elements).
+ * Total over everything acx_qap_h accepts: a transform size the distributed four-step form does not cover (N above 2^24, or
+ * fewer than 2 * n_devices points per digit) is answered from ONE device, on a copy of the whole system it receives on the
+ * first such call.  Only a system loaded with ACX_MGPU_VERIFY_ONLY refuses (ACX_ERR_UNSUPPORTED). */
 int acx_mgpu_qap_h(acx_mgpu_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok);
 /* `createPolynomialsFFT primRoots genQap` (src/QAP.hs:512-525) for a wire range of one matrix, the wires shared out over
  * the devices (columns are independent: no exchange at all): arguments and results of acx_qap_columns, every

@@ -355,3 +355,37 @@ def test_mgpu_qap_columns_gate_mix_and_small_system(acx, request):
     assert ms.n_shards == 1
     cols, _ = ms.qap_columns(0, 0, 16)
     assert np.array_equal(cols, orc.qap_columns(300, ms.log_n, small.rows()[0], 0, 16, nthreads=4))
+
+
+def test_mgpu_qap_h_outside_the_distributed_range_answers_from_one_device(acx, request):
+    """A sharded system whose transform size the four-step form does not cover (here N = 2^11 on 32 shards: fewer than 2 W
+    points per digit; in production N above 2^24): verifyAssignment runs on the slabs as always, verificationWitness still answers -- from one device, on its
+    copy of the whole system -- bit-equal to the oracle; only a VERIFY_ONLY load refuses."""
+    synth = acx.synth
+    mg = _mg(acx, request, "bn254", [0] * 32)
+    mg.set_shard_threshold(10)
+    orc = _orc(request, "bn254")
+    n = 1500
+    s = synth.mulgraph(n, n_in=16, window=64, seed=0xF411, field="bn254")
+    mats, w = s.rows(), s.witness()
+    mr = mg.from_circuit(s.circuit)
+    assert (mr.n_shards, mr.log_n) == (32, 11)
+    assert mr.verify(w) == (True, 0, U64_MAX)
+    delta = [11, 22, R.BN254.p - 33]
+    for d in (None, delta):
+        h, ok = mr.qap_h(w, d)
+        want, want_ok = orc.qap_h(n, mr.m, 11, *mats, w, delta=d)
+        assert ok and want_ok and np.array_equal(h, want[: h.shape[0]]) and not want[h.shape[0]:].any()
+    bad = w.copy()
+    bad[40, 0] ^= np.uint64(1)
+    assert mr.qap_h(bad) == (None, False)
+    cols, _ = mr.qap_columns(0, 0, 9)
+    assert np.array_equal(cols, orc.qap_columns(n, 11, mats[0], 0, 9))
+    with pytest.raises(acx.AcxError) as e:                       # the resident pipeline itself stays refused
+        mr.upload_witness(w)
+        mr.qap_h_resident()
+    assert e.value.status == acx._lib.STATUS["UNSUPPORTED"]
+    mv = mg.from_circuit(s.circuit, verify_only=True)
+    with pytest.raises(acx.AcxError) as e:
+        mv.qap_h(w)
+    assert e.value.status == acx._lib.STATUS["UNSUPPORTED"]
