@@ -227,6 +227,7 @@ struct acx_r1cs {
     uint4* d_w = nullptr;  // the witness acx_r1cs_eval leaves resident (m elements); acx_naive_h uses it as scratch
     bool resident_valid = false;                     // d_w holds a witness produced by acx_r1cs_eval
     uint4* qh = nullptr;   // h(x) pipeline scratch, 5N elements (allocated on first use)
+    uint4* d_hscale = nullptr;       // {1/z, -1/z} as dev elements: the factors the h(x) pipeline lets ride on the stored dot products
 };
 
 struct acx_batch {
@@ -549,8 +550,13 @@ inline int r4_pick_lg(int lp, int want) {      // largest compiled LG <= want, o
 // post_batches (with post_mont): only the first post_batches vectors of the batch take the post factor, the others end as a
 // plain inverse transform; *post_limited reports whether this plan could do that (it needs 1/N folded into the twiddles, i.e.
 // two or more passes) -- if not, every vector takes the factor.
+// in_a, in_b (both or neither; batch 1, two or more r4 passes): the transform of the POINTWISE PRODUCT in_a[i] * in_b[i] lands in d
+// -- the product is formed as the first pass loads its points, no vector of products ever exists.  add_out: a vector added to
+// the output behind the closing step, d[k] = X[k] + add_out[k].  (h(x): the last transform takes L * R on the way in and the
+// coefficient-domain -O/z on the way out.)  ACX_ERR_UNSUPPORTED when the plan of this size cannot do it: nothing was launched.
 int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inverse, const H256* shift_mont,
-                   const H256* post_mont = nullptr, uint64_t post_batches = 0, bool* post_limited = nullptr) {
+                   const H256* post_mont = nullptr, uint64_t post_batches = 0, bool* post_limited = nullptr,
+                   const uint4* in_a = nullptr, const uint4* in_b = nullptr, const uint4* add_out = nullptr) {
     if (post_limited) *post_limited = false;
     if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
     if (batch == 0) return ACX_OK;
@@ -597,6 +603,8 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         for (int q = p + 1; q < P; ++q) Wt[p] <<= lg[q];
         for (int q = 0; q < p; ++q) Vt[p] <<= lg[q];
     }
+    if ((in_a || in_b || add_out) && (!r4 || P < 2 || batch != 1 || !in_a != !in_b))
+        return fail(ACX_ERR_UNSUPPORTED, "no fused product / sum for this transform");
     uint4* scratch = nullptr;
     if (P > 1) {
         const size_t need = (size_t)batch * N * 32;
@@ -628,8 +636,10 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         NttPass Q;
         std::memset(&Q, 0, sizeof(Q));
         const bool last = p == P - 1, first = p == 0;
-        Q.src = first ? d : scratch;
+        Q.src = first ? (in_a ? in_a : d) : scratch;
         Q.dst = last ? d : scratch;
+        if (first && in_b) Q.mul_src = in_b;
+        if (last && add_out) Q.add_src = add_out;
         Q.log_s = lg[p];
         if (lg[p] > 0) {
             uint4* st = nullptr;
@@ -707,6 +717,10 @@ int ntt_dev_locked(acx_ctx* c, uint4* d, uint32_t log_n, uint64_t batch, int inv
         Q.n_outer = no;
         Q.log_t = ilog2(T);
         if (first && !inverse && shift_mont) Q.scale_on_load = 1;
+        if (first && in_b) {
+            if (Q.scale_on_load) return fail(ACX_ERR_UNSUPPORTED, "no fused product on a forward coset transform");
+            Q.scale_on_load = 3;
+        }
         if (last) {
             // the closing multiplication: 1 (forward), 1/N (inverse), 1/N * g^-k (inverse coset)
             // (the coset tables of an inverse transform already carry 1/N)
@@ -950,10 +964,11 @@ int launch_long_rows(acx_r1cs* r, const uint4* d_w, const ResidualOut& out, cons
 }
 
 int launch_residual(acx_r1cs* r, const uint4* d_w, uint64_t row_offset, unsigned long long* d_result,
-                    uint4* d_res, uint4* d_dots, uint64_t dots_stride, uint32_t map_log_run = 0, uint32_t map_log_r = 0) {
+                    uint4* d_res, uint4* d_dots, uint64_t dots_stride, uint32_t map_log_run = 0, uint32_t map_log_r = 0,
+                    const uint4* dot_scale = nullptr) {
     acx_ctx* c = r->ctx;
     if (r->n == 0) return ACX_OK;
-    const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset, map_log_run, map_log_r};
+    const ResidualOut out{d_result, d_res, d_dots, dots_stride, row_offset, map_log_run, map_log_r, dot_scale};
     const SellSystem S = sell_system(r, d_w, out);
     const dim3 grid(sell_grid_x(r->n_slices), 1, 1);
     launch_sell(c, sell_spec(r), grid, nullptr, S);
@@ -1169,6 +1184,7 @@ void free_r1cs_device(acx_r1cs* r) {
     r->ev_items = r->ev_row = r->ev_wire_ofs = r->ev_wires = nullptr; r->ev_kind = nullptr;
     if (r->d_w) (void)hipFree(r->d_w);
     if (r->qh) (void)hipFree(r->qh);
+    if (r->d_hscale) (void)hipFree(r->d_hscale);
     r->perm = nullptr; r->long_rows = nullptr; r->d_w = nullptr; r->qh = nullptr;
 }
 
@@ -1245,6 +1261,16 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* const ma
         if (rc == ACX_OK) {
             hipError_t e = hipMalloc((void**)&r->d_w, m * 32);
             if (e != hipSuccess) rc = fail(ACX_ERR_OOM, "witness buffer allocation failed");
+        }
+        if (rc == ACX_OK && (int)log_n + 1 <= ctx->hf.two_adicity()) {
+            // {1/z, -1/z}, z = g^N - 1 (the target polynomial on the coset g<omega>): the factors the h(x) pipeline lets ride
+            // on the stored dot products.  They depend on N alone; made here so that concurrent callers find them ready.
+            const HostField& hf = ctx->hf;
+            const H256 zinv = hf.inv(hf.sub(hf.pow_u64(hf.generator(), 1ull << log_n), hf.one()));
+            const H256 pair[2] = {hf.to_dev_word(zinv), hf.to_dev_word(hf.sub(hf.zero(), zinv))};
+            hipError_t e = hipMalloc((void**)&r->d_hscale, 64);
+            if (e == hipSuccess) e = hipMemcpy(r->d_hscale, pair, 64, hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = fail(ACX_ERR_HIP, "h(x) constants");
         }
     } catch (const std::bad_alloc&) {
         rc = fail(ACX_ERR_OOM, "host allocation failed");
@@ -1943,10 +1969,15 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
     uint4* keep = d + 6 * N;                                          // dots (3N) + kept L0, R0 (2N)
     if (N > r->n)                                                    // rows n..N-1 are the zero padding
         for (int k = 0; k < 3; ++k) HIP_TRY(hipMemsetAsync(d + 2 * ((uint64_t)k * N + r->n), 0, (N - r->n) * 32, cur_stream(c)));
-    ACX_TRY(launch_residual(r, d_w, 0, d_result, nullptr, d, N));
     const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
-    // coset: shift = multiplicative generator g (g^N != 1)
+    // coset: shift = multiplicative generator g (g^N != 1); z = g^N - 1 is the target polynomial on it
     const H256 g = hf.generator();
+    const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
+    const H256 mzinv = hf.sub(hf.zero(), zinv);
+    // Without the zero-knowledge terms 1/z and -1/z ride on the stored dot products (one product per row in a launch that waits
+    // for memory): (L/z) R - O/z is then what the rest of the pipeline forms, with no pass over the product and no scaled
+    // subtraction.  The two constants live beside the system (they depend on N alone: r1cs_from_host).
+    ACX_TRY(launch_residual(r, d_w, 0, d_result, nullptr, d, N, 0, 0, zk ? nullptr : (const uint4*)r->d_hscale));
     // evaluations on <omega> -> coefficients of L0, R0, O0; L0 and R0 -> evaluations on g<omega>.  O0 stays in coefficient
     // form: h = icoset((L R - O)/z) = icoset(L R / z) - O0 / z by linearity (icoset after coset is the identity), which
     // drops one of the seven transforms.  Without the zero-knowledge terms nobody needs the plain coefficients of L0 and
@@ -1964,12 +1995,10 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
         if (zk) HIP_TRY(hipMemcpyAsync(keep, d, 2 * N * 32, hipMemcpyDeviceToDevice, cur_stream(c)));
         ACX_TRY(ntt_dev_locked(c, d, r->log_n, 2, 0, &g));
     }
-    const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
-    DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d,
-                                         (const uint4*)(d + 2 * N), (const uint4*)nullptr, d_h, N, dev_arg(hf, zinv), zk ? 0u : 1u));
-    ACX_TRY(ntt_dev_locked(c, d_h, r->log_n, 1, 1, &g));
-    const H256 mzinv = hf.sub(hf.zero(), zinv);
     if (zk) {
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d,
+                                             (const uint4*)(d + 2 * N), (const uint4*)nullptr, d_h, N, dev_arg(hf, zinv), 0u));
+        ACX_TRY(ntt_dev_locked(c, d_h, r->log_n, 1, 1, &g));
         // (L0+d1 T)(R0+d2 T) - (O0+d3 T) = T * (h0 + d1 R0 + d2 L0 + d1 d2 T - d3),  T = x^N - 1
         const uint4* L0 = keep;
         const uint4* R0 = L0 + 2 * N;
@@ -1979,14 +2008,33 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
                                dev_arg(hf, dl[0]), dev_arg(hf, dl[1]), dev_arg(hf, mzinv));
             hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, cur_stream(c), d_h, N, dev_arg(hf, hf.add(d12, dl[2])), dev_arg(hf, d12));
         });
-    } else if (fused == ACX_OK && !o_plain) {
+        HIP_TRY(hipGetLastError());
+        return ACX_OK;
+    }
+    // d = (L/z) on the coset, d + N = R on the coset, O0 = -O/z in coefficient form (times g^i when !o_plain of a fused launch).
+    // The last transform takes the product as its first pass loads the points and adds O0 behind its closing step -- where
+    // the plan of this size can (two or more passes of k_ntt_r4); otherwise the two passes over the vectors run as kernels.
+    const bool o_has_g = fused == ACX_OK && !o_plain;
+    const H256 one = hf.one();
+    const int last = ntt_dev_locked(c, d_h, r->log_n, 1, 1, &g, nullptr, 0, nullptr, d, d + 2 * N, o_has_g ? nullptr : O0);
+    bool o_added = last == ACX_OK && !o_has_g;
+    if (last == ACX_OK) {
+        HIP_TRY(hipMemsetAsync(d_h + 2 * N, 0, 32, cur_stream(c)));                          // h has N + 1 coefficients
+    } else if (last == ACX_ERR_UNSUPPORTED) {
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), (const uint4*)d,
+                                             (const uint4*)(d + 2 * N), (const uint4*)nullptr, d_h, N, dev_arg(hf, one), 1u));
+        ACX_TRY(ntt_dev_locked(c, d_h, r->log_n, 1, 1, &g));
+    } else {
+        return last;
+    }
+    if (o_has_g) {
         uint4 *glo = nullptr, *ghi = nullptr;
         ACX_TRY(get_coset_tables(c, hf.inv(g), r->log_n, 0, &glo, &ghi, 0));
         DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy_geo<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, (const uint4*)O0, N,
-                                             (const uint4*)glo, (const uint4*)ghi, dev_arg(hf, mzinv)));
-    } else {
+                                             (const uint4*)glo, (const uint4*)ghi, dev_arg(hf, one)));
+    } else if (!o_added) {
         DISPATCH_FIELD(c, hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(c, N)), dim3(kBlock), 0, cur_stream(c), d_h, (const uint4*)nullptr,
-                                             (const uint4*)nullptr, (const uint4*)O0, N, dev_arg(hf, mzinv), dev_arg(hf, mzinv), dev_arg(hf, mzinv)));
+                                             (const uint4*)nullptr, (const uint4*)O0, N, dev_arg(hf, one), dev_arg(hf, one), dev_arg(hf, one)));
     }
     HIP_TRY(hipGetLastError());
     return ACX_OK;

@@ -114,6 +114,12 @@ public:
         for (int i = k; i < two_adicity_; ++i) w = mul(w, w);
         return w;
     }
+    // Device element of a host Montgomery value as it lies in device MEMORY: x * 2^261 mod p, 32 bytes little endian.
+    H256 to_dev_word(const H256& mont) const {
+        H256 y = mont;
+        for (int i = 0; i < 5; ++i) y = add(y, y);
+        return y;
+    }
     // Device element (lazy Montgomery radix 2^261) of a host Montgomery value, as 9 x 29-bit limbs.
     void to_dev_limbs(const H256& mont, uint32_t out[9]) const {
         // stored integer of mont = x*2^256 mod p; x*2^261 mod p = 32 * that (mod p)

@@ -281,6 +281,10 @@ struct ResidualOut {
     // of every 2^map_log_r -- local row j is global row row_offset + (j mod run) + (j / run) * 2^map_log_r.  Only
     // evaluated on the (rare) violated-row path.
     u32 map_log_run, map_log_r;
+    // null, or two dev elements {sa, sc}: the STORED <A_i,w> is multiplied by sa and the stored <C_i,w> by sc (the residual is
+    // formed from the plain values).  h(x) lets 1/z and -1/z ride on the dots: (sa L) R + sc O = (L R - O) / z needs neither a
+    // pointwise pass over the product nor a scaled subtraction afterwards.
+    const uint4* dot_scale;
 };
 
 // per-lane epilogue shared by the SELL and the CSR-rows kernels.  Violations are the rare case: a
@@ -294,9 +298,10 @@ __device__ __forceinline__ void residual_epilogue(const Fe& a, const Fe& b, cons
         bad = !fe_is_zero<F>(r);
         if (out.residuals != nullptr) fe_store(out.residuals + 2 * (u64)row, r);
         if (out.dots != nullptr) {
-            fe_store(out.dots + 2 * (u64)row, a);
+            const bool scaled = out.dot_scale != nullptr;          // uniform
+            fe_store(out.dots + 2 * (u64)row, scaled ? fe_mul<F>(a, fe_load(out.dot_scale)) : a);
             fe_store(out.dots + 2 * (out.dots_stride + row), b);
-            fe_store(out.dots + 2 * (2 * out.dots_stride + row), c);
+            fe_store(out.dots + 2 * (2 * out.dots_stride + row), scaled ? fe_mul<F>(c, fe_load(out.dot_scale + 2)) : c);
         }
     }
     const unsigned long long mask = __ballot(bad);

@@ -36,12 +36,14 @@ struct NttPass {
     const uint4* tw_hi;    // high level (w^(1024 j)) or null
     const uint4* sc_lo;    // coset powers g^j (j < 1024) or null
     const uint4* sc_hi;    // g^(1024 j) or null
+    const uint4* mul_src;  // (k_ntt_r4, scale_on_load 3) second input vector: the pass transforms src[i] * mul_src[i]
+    const uint4* add_src;  // (k_ntt_r4, last pass) null, or a vector added to the output after the closing step: dst[k] = closing(X[k]) + add_src[k]
     u32 log_s, log_t;      // S points, T columns
     u32 n_outer;
     u32 tw_mode;           // 0 none, 1 direct table index (I*K) >> tw_shift, 2 two-level on (I*K) & tw_mask, 3 (k_ntt_r4) table in store order: tw_lo[output offset]
     u32 tw_shift;
     u32 scale_mode;        // 0 none, 1 multiply by `scale`, 2 scale * g^(element index) via sc_lo/sc_hi, 3 (k_ntt_r4) g^(index) from the direct table sc_lo
-    u32 scale_on_load;     // coset pre-multiplication of a forward transform (first pass): 1 two-level by element index, 2 (k_ntt_r4) sc_lo[transform digit]
+    u32 scale_on_load;     // coset pre-multiplication of a forward transform (first pass): 1 two-level by element index, 2 (k_ntt_r4) sc_lo[transform digit], 3 (k_ntt_r4) the element of mul_src at the same offset
     u32 pad;
     u64 scale_off_end;     // scale_mode 3 (k_ntt_r4): outputs at offsets >= this take the plain reduction (0 = no bound): the
                            // leading vectors of a batch get the coset factor, the rest do not (h(x): L and R, not O)

@@ -153,6 +153,8 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
                 Fe f;
                 if (P.scale_on_load == 2) {  // by the transform digit alone, from a direct table of S entries (distributed steps)
                     f = fe_load(P.sc_lo + 2 * (u64)d);
+                } else if (P.scale_on_load == 3) {  // pointwise product of two vectors on the way in (h(x): L * R on the coset)
+                    f = fe_load(P.mul_src + 2 * (cbase + (u64)(d & smask) * P.stride_t_in + (u64)(d >> P.split_in) * P.stride_t_in_hi));
                 } else {
                     const u64 off = cbase + (u64)(d & smask) * P.stride_t_in + (u64)(d >> P.split_in) * P.stride_t_in_hi;
                     const u64 ex = P.e_mode ? (P.e_base + (u64)d * P.e_t + (P.i_base + I0 + (u64)col * P.c_iw) * P.e_c) : (off & P.idx_mask);
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
         }
         Fe y;
         if (mul) y = fe_mul<F>(cur, f); else y = fe_reduce_loose<F>(cur);
+        if (P.add_src != nullptr) y = fe_add<F>(y, fe_load(P.add_src + 2 * off));     // uniform
         fe_store(P.dst + 2 * off, y);
     }
 }
