@@ -799,7 +799,10 @@ int get_dist_table(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, u
 // rows_transposed (inverse step 0 only): the input is the ROWS block stored TRANSPOSED, [k2][kl] -- the ascending row order in
 // which the residual kernel of a block-cyclic shard writes its dot products (mgpu.inc.h) -- instead of [kl][k2].
 int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
-                         const H256* shift_mont, const uint4* in, uint4* out, bool rows_transposed = false) {
+                         const H256* shift_mont, const uint4* in, uint4* out, bool rows_transposed = false,
+                         const uint4* mul_in = nullptr, const uint4* add_out = nullptr) {
+    // mul_in: the step transforms in[i] * mul_in[i] (same layout as in); add_out: out[k] = (closing step)(X[k]) + add_out[k]
+    // (same layout as out) -- the h(x) pipeline's product of L and R and its coefficient-domain -O/z (qap_h_dev_locked)
     const HostField& hf = c->hf;
     const NttCfg& cfg = c->ntt;
     if ((int)log_n > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
@@ -896,6 +899,11 @@ int ntt_dist_step_locked(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t wo
         ACX_TRY(get_dist_table(c, log_n, log_r, world, rank, 2, &ginv, &tw));
         Q.tw_mode = 3; Q.tw_lo = tw;
     }
+    if (mul_in) {
+        if (Q.scale_on_load) return fail(ACX_ERR_UNSUPPORTED, "no fused product on a forward coset step");
+        Q.mul_src = mul_in; Q.scale_on_load = 3;
+    }
+    Q.add_src = add_out;
     const uint64_t tiles = cols / T;
     const bool ok = launch_ntt_r4(c->field == ACX_FIELD_BLS12_381_FR, lp, lgrp, (unsigned)tiles, cur_stream(c), Q);
     if (!ok) return fail(ACX_ERR_UNSUPPORTED, "distributed NTT step: kernel instance missing");

@@ -150,6 +150,7 @@ struct acx_mgpu_r1cs {
         acx_r1cs* full = nullptr;                   // the WHOLE system, for this shard's wires of acx_mgpu_qap_columns (built on its first call)
         uint4* d_w = nullptr;                       // the replicated witness, m dev elements
         uint4* vec = nullptr;                       // h(x) pipeline: dots 3L | coef 3L | pw L | h L (allocated on first use)
+        uint4* hscale = nullptr;                    // {1/z, -1/z} for the GLOBAL N as dev elements: ride on the stored dots of h(x) (qap_h_dev_locked)
         unsigned long long* ring = nullptr;         // kMgRing result slots {n_bad, first_bad} of the asynchronous form + their reduction
     };
     std::vector<Part> part;
@@ -267,7 +268,8 @@ struct MgNtt {
 
     // in[s]: L dev elements per shard (COLS for a forward, ROWS for an inverse transform)
     // rows_transposed: the input of an inverse transform is in ascending row order [k2][kl] (the residual kernel's dots)
-    int begin(int k, uint4* const* in, int inverse, const H256* shift, bool rows_transposed = false) {
+    // mul: the transform of the pointwise product in[s][i] * mul[s][i] (same layout)
+    int begin(int k, uint4* const* in, int inverse, const H256* shift, bool rows_transposed = false, uint4* const* mul = nullptr) {
         const uint32_t W = mg->W;
         for (uint32_t s = 0; s < W; ++s) {
             MgShard& S = mg->sh[s];
@@ -276,20 +278,23 @@ struct MgNtt {
             if (!mg->rccl)                                          // peers still pulling the previous contents of send
                 for (uint32_t t = 0; t < W; ++t)
                     if (mg->sh[t].slot[k].got_valid) HIP_TRY(hipStreamWaitEvent(S.ctx->stream, mg->sh[t].slot[k].got, 0));
-            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 0, shift, in[s], S.slot[k].send, rows_transposed));
+            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 0, shift, in[s], S.slot[k].send, rows_transposed,
+                                         mul ? mul[s] : nullptr));
             HIP_TRY(hipEventRecord(S.slot[k].sent, S.ctx->stream));
         }
         return exchange(k);
     }
 
-    int finish(int k, uint4* const* out, int inverse, const H256* shift) {
+    // add: out[s][k] = X[k] + add[s][k] (same layout as out)
+    int finish(int k, uint4* const* out, int inverse, const H256* shift, uint4* const* add = nullptr) {
         const uint32_t W = mg->W;
         for (uint32_t s = 0; s < W; ++s) {
             MgShard& S = mg->sh[s];
             HIP_TRY(hipSetDevice(S.device));
             CtxLock lock(S.ctx->mu);
             HIP_TRY(hipStreamWaitEvent(S.ctx->stream, S.slot[k].got, 0));
-            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 1, shift, S.slot[k].recv, out[s]));
+            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 1, shift, S.slot[k].recv, out[s], false, nullptr,
+                                         add ? add[s] : nullptr));
             HIP_TRY(hipEventRecord(S.slot[k].used, S.ctx->stream));
             S.slot[k].used_valid = true;
         }
@@ -355,7 +360,7 @@ int mg_upload_witness(acx_mgpu_r1cs* mr, const acx_fr* witness) {
 // Two halves, so that h(x) can issue its whole pipeline between them and the host waits once, at the end.
 // mg_residual_enqueue: the residual launch on every shard (+ dots when the h(x) pipeline follows) and, with RCCL, THE verdict
 // collective behind it -- everything asynchronous.  mg_residual_fetch: the verdict (one wait).
-int mg_residual_enqueue(acx_mgpu_r1cs* mr, bool with_dots) {
+int mg_residual_enqueue(acx_mgpu_r1cs* mr, bool with_dots, bool scaled_dots = false) {
     acx_mgpu* mg = mr->mg;
     const uint32_t W = mg->W;
     const uint64_t L = (1ull << mr->log_n) / W, rw = (1ull << mr->log_r) / W;
@@ -367,7 +372,8 @@ int mg_residual_enqueue(acx_mgpu_r1cs* mr, bool with_dots) {
         HIP_TRY(hipMemcpyAsync(S.d_res, init, 16, hipMemcpyHostToDevice, S.ctx->stream));      // the canonicity flag stays
         const auto& P = mr->part[s];
         if (with_dots)          // the block-cyclic copy: dots in ascending row order (= ROWS transposed), first_bad through the run map
-            ACX_TRY(launch_residual(P.cyc, P.d_w, (uint64_t)s * rw, S.d_res, nullptr, P.vec, L, mr->log_r - mg_log2(W), mr->log_r));
+            ACX_TRY(launch_residual(P.cyc, P.d_w, (uint64_t)s * rw, S.d_res, nullptr, P.vec, L, mr->log_r - mg_log2(W), mr->log_r,
+                                    scaled_dots ? (const uint4*)P.hscale : nullptr));
         else
             ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, S.d_res, nullptr, nullptr, 0));
     }
@@ -561,6 +567,7 @@ void mg_free_r1cs(acx_mgpu_r1cs* mr) {
         if (p.d_w) (void)hipFree(p.d_w);
         if (p.vec) (void)hipFree(p.vec);
         if (p.ring) (void)hipFree(p.ring);
+        if (p.hscale) (void)hipFree(p.hscale);
     }
     delete mr;
 }
@@ -646,6 +653,13 @@ int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], 
             ACX_TRY(r1cs_from_host(mg->sh[s].ctx, L, m, mp, &P.cyc));
         }
         HIP_TRY(hipMalloc((void**)&P.d_w, m * 32));
+        if (mr->has_cyclic && (int)log_n + 1 <= mg->sh[s].ctx->hf.two_adicity()) {
+            const HostField& hf = mg->sh[s].ctx->hf;
+            const H256 zinv = hf.inv(hf.sub(hf.pow_u64(hf.generator(), 1ull << log_n), hf.one()));
+            const H256 pair[2] = {hf.to_dev_word(zinv), hf.to_dev_word(hf.sub(hf.zero(), zinv))};
+            HIP_TRY(hipMalloc((void**)&P.hscale, 64));
+            HIP_TRY(hipMemcpy(P.hscale, pair, 64, hipMemcpyHostToDevice));
+        }
         HIP_TRY(hipMalloc((void**)&P.ring, 2 * 2 * kMgRing * 8));
         std::vector<unsigned long long> init(2 * 2 * kMgRing);
         for (uint32_t i = 0; i < 2 * kMgRing; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
@@ -725,8 +739,11 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
             HIP_TRY(hipMalloc((void**)&mr->part[s].vec, 8 * L * 32));
         }
     mr->h_valid = false;
-    ACX_TRY(mg_residual_enqueue(mr, true));         // the verdict is fetched after the whole pipeline has been issued: one wait
     const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
+    // without the zero-knowledge terms 1/z and -1/z ride on the stored dots, the last transform takes (L/z) * R as its first
+    // step loads the points and adds -O/z behind its closing step (qap_h_dev_locked's fused form, sharded)
+    const bool fusedh = !zk && mr->part[0].hscale != nullptr;
+    ACX_TRY(mg_residual_enqueue(mr, true, fusedh)); // the verdict is fetched after the whole pipeline has been issued: one wait
     const H256 g = hf.generator();
     MgNtt nt(mg, mr->log_n, mr->log_r);
     auto ptrs = [&](uint64_t off) { std::vector<uint4*> v(W); for (uint32_t s = 0; s < W; ++s) v[s] = mr->part[s].vec + 2 * off; return v; };
@@ -742,18 +759,23 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
     for (int k = 0; k < 2; ++k) ACX_TRY(nt.finish(k, ptrs((uint64_t)k * L).data(), 0, &g));
     const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
     const H256 mzinv = hf.sub(hf.zero(), zinv);
-    for (uint32_t s = 0; s < W; ++s) {
-        MgShard& S = mg->sh[s];
-        HIP_TRY(hipSetDevice(S.device));
-        CtxLock lock(S.ctx->mu);
-        uint4* v = mr->part[s].vec;
-        DISPATCH_FIELD(S.ctx, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(S.ctx, L)), dim3(kBlock), 0, S.ctx->stream, (const uint4*)v,
-                                                 (const uint4*)(v + 2 * L), (const uint4*)nullptr, v + 2 * 6 * L, L, dev_arg(hf, zinv), 0u));
-        HIP_TRY(hipGetLastError());
+    if (fusedh) {
+        ACX_TRY(nt.begin(0, ptrs(0).data(), 1, &g, false, ptrs(L).data()));
+        ACX_TRY(nt.finish(0, ptrs(7 * L).data(), 1, &g, ptrs(5 * L).data()));
+    } else {
+        for (uint32_t s = 0; s < W; ++s) {
+            MgShard& S = mg->sh[s];
+            HIP_TRY(hipSetDevice(S.device));
+            CtxLock lock(S.ctx->mu);
+            uint4* v = mr->part[s].vec;
+            DISPATCH_FIELD(S.ctx, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(S.ctx, L)), dim3(kBlock), 0, S.ctx->stream, (const uint4*)v,
+                                                     (const uint4*)(v + 2 * L), (const uint4*)nullptr, v + 2 * 6 * L, L, dev_arg(hf, zinv), 0u));
+            HIP_TRY(hipGetLastError());
+        }
+        ACX_TRY(nt.begin(0, ptrs(6 * L).data(), 1, &g));
+        ACX_TRY(nt.finish(0, ptrs(7 * L).data(), 1, &g));
     }
-    ACX_TRY(nt.begin(0, ptrs(6 * L).data(), 1, &g));
-    ACX_TRY(nt.finish(0, ptrs(7 * L).data(), 1, &g));
-    for (uint32_t s = 0; s < W; ++s) {
+    for (uint32_t s = 0; s < W && !fusedh; ++s) {
         MgShard& S = mg->sh[s];
         HIP_TRY(hipSetDevice(S.device));
         CtxLock lock(S.ctx->mu);

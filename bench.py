@@ -207,7 +207,7 @@ def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
     b_r1cs, nnz, _ = algorithmic_bytes(mats, n)
     alg = 7 * 128 * n + (b_r1cs + 3 * 32 * n) + 5 * 32 * n     # SURVEY.md 8(d)'s definition of the job: 7 NTTs + residual-style dots (written) + pointwise
     ops = 6 * (1.5 * n * log_n) + 4 * n + nnz + 2 * n           # butterflies of the SIX transforms actually run, scalings, dot-product MACs, pointwise + O / z
-    return {"workload": f"verificationWitness h(x), 2^{log_n}-constraint mulgraph ({field} Fr), device resident: residual dots + 6 NTTs (O stays in coefficient form) + pointwise", "transforms": 6,
+    return {"workload": f"verificationWitness h(x), 2^{log_n}-constraint mulgraph ({field} Fr), device resident: residual dots (1/z, -1/z riding on them) + 6 NTTs (O stays in coefficient form; the last one takes L*R on load and adds -O/z on store)", "transforms": 6,
             "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6, "roofline": _hbm(alg, us)}
 
 
