@@ -93,6 +93,8 @@ SYMBOLS = {
     "acx_qap_sub_o_dev": (_I, [_P, _U32, _U64, _P, _P, _P]),
     "acx_ntt_dist_step_dev": (_I, [_P, _U32, _U32, _U32, _U32, _I, _I, _P, _P, _P]),
     "acx_ntt_dist_step_ex_dev": (_I, [_P, _U32, _U32, _U32, _U32, _I, _I, _U32, _P, _P, _P]),
+    "acx_ntt_dist_step_fused_dev": (_I, [_P, _U32, _U32, _U32, _U32, _I, _I, _U32, _P, _P, _P, _P, _P]),
+    "acx_r1cs_dots_h_dev": (_I, [_P, _P, _U64, _P, _P, _U32, _P]),
     "acx_batch_create": (_I, [_P, _U64, _P, _P, _P, _U64, C.POINTER(_P)]),
     "acx_batch_verify_dev": (_I, [_P]),
     "acx_batch_destroy": (None, [_P]),

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <atomic>
 #include <list>
+#include <array>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -124,6 +125,7 @@ struct acx_ctx {
         }
     };
     std::map<DistKey, uint4*> tw_dist;
+    std::map<std::pair<uint32_t, std::array<uint64_t, 4>>, uint4*> h_scale;   // (log_n, coset shift) -> {1/z, -1/z} of the h(x) pipeline (get_h_scale)
     NttCfg ntt;
     bool small_coeff = true;                               // use the small-coefficient SELL form where a matrix allows it
     uint4* ntt_scratch = nullptr;                          // ping-pong buffer of the multi-pass NTT
@@ -1461,6 +1463,7 @@ void acx_ctx_destroy(acx_ctx* c) {
     for (auto& kv : c->tw_scaled) (void)hipFree(kv.second);
     for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
     for (auto& kv : c->tw_dist) (void)hipFree(kv.second);
+    for (auto& kv : c->h_scale) (void)hipFree(kv.second);
     if (c->ntt_scratch) (void)hipFree(c->ntt_scratch);
     for (auto& e : c->cosets) { if (e.lo) (void)hipFree(e.lo); if (e.hi) (void)hipFree(e.hi); }
     c->cosets.clear();
@@ -2187,6 +2190,44 @@ int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset,
                            (uint4*)d_residuals, (uint4*)d_dots, 1ull << r->log_n);
 }
 
+// {1/z, -1/z}, z = g^N - 1, for N = 2^log_n and the coset shift g (Montgomery) as two dev elements, cached per context
+// (caller holds c->mu): what the h(x) pipeline lets ride on the stored dot products (qap_h_dev_locked).  A rank of a
+// distributed job needs them for the GLOBAL N, which its own system (N / world rows) does not know.
+static int get_h_scale(acx_ctx* c, uint32_t log_n, const H256& g, const uint4** out) {
+    const HostField& hf = c->hf;
+    if ((int)log_n + 1 > hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "coset needs log_n + 1 <= two-adicity");
+    const std::pair<uint32_t, std::array<uint64_t, 4>> key{log_n, {g.l[0], g.l[1], g.l[2], g.l[3]}};
+    auto it = c->h_scale.find(key);
+    if (it != c->h_scale.end()) { *out = it->second; return ACX_OK; }
+    const H256 z = hf.sub(hf.pow_u64(g, 1ull << log_n), hf.one());
+    if (z.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift lies in the transform's own subgroup (shift^N = 1)");
+    const H256 zinv = hf.inv(z);
+    const H256 pair[2] = {hf.to_dev_word(zinv), hf.to_dev_word(hf.sub(hf.zero(), zinv))};
+    uint4* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 64));
+    const hipError_t e = hipMemcpy(d, pair, 64, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); HIP_TRY(e); }
+    c->h_scale[key] = d;
+    *out = d;
+    return ACX_OK;
+}
+
+int acx_r1cs_dots_h_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset, uint64_t* d_result, void* d_dots, uint32_t h_log_n,
+                        const acx_fr* shift) {
+    if (!r || !d_witness || !d_result || !d_dots) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    CtxLock lock(r->ctx->mu);
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    H256 g = r->ctx->hf.generator();
+    if (shift) {
+        ACX_TRY(read_h256(shift, r->ctx->hf, g));
+        if (g.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift must be nonzero");
+    }
+    const uint4* scale = nullptr;
+    ACX_TRY(get_h_scale(r->ctx, h_log_n, g, &scale));
+    return launch_residual(r, (const uint4*)d_witness, row_offset, (unsigned long long*)d_result, nullptr, (uint4*)d_dots,
+                           1ull << r->log_n, 0, 0, scale);
+}
+
 int acx_qap_pointwise_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_fr* shift, const void* d_a, const void* d_b,
                           const void* d_c, void* d_out) {
     if (!c || !shift || !d_a || !d_b || !d_out) return fail(ACX_ERR_INVALID_ARG, "null argument");      // d_c may be NULL
@@ -2223,7 +2264,14 @@ int acx_qap_sub_o_dev(acx_ctx* c, uint32_t log_n, uint64_t count, const acx_fr* 
 
 int acx_ntt_dist_step_ex_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
                              uint32_t flags, const acx_fr* shift, const void* d_in, void* d_out) {
+    return acx_ntt_dist_step_fused_dev(c, log_n, log_r, world, rank, inverse, step, flags, shift, d_in, nullptr, nullptr, d_out);
+}
+
+int acx_ntt_dist_step_fused_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
+                                uint32_t flags, const acx_fr* shift, const void* d_in, const void* d_mul, const void* d_add, void* d_out) {
     if (!c || !d_in || !d_out || (step != 0 && step != 1)) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    if (d_mul && !inverse && step == 0 && shift) return fail(ACX_ERR_UNSUPPORTED, "no product on load of a forward coset step");
+    if (d_add == d_out || d_mul == d_out) return fail(ACX_ERR_INVALID_ARG, "steps are out of place");
     if (flags & ~(uint32_t)ACX_DIST_ROWS_T) return fail(ACX_ERR_INVALID_ARG, "unknown flag");
     if ((flags & ACX_DIST_ROWS_T) && !(inverse && step == 0)) return fail(ACX_ERR_INVALID_ARG, "ACX_DIST_ROWS_T applies to inverse step 0");
     CtxLock lock(c->mu);
@@ -2234,7 +2282,7 @@ int acx_ntt_dist_step_ex_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_
         if (sh.is_zero()) return fail(ACX_ERR_INVALID_ARG, "coset shift must be nonzero");
     }
     return ntt_dist_step_locked(c, log_n, log_r, world, rank, inverse, step, shift ? &sh : nullptr, (const uint4*)d_in,
-                                (uint4*)d_out, (flags & ACX_DIST_ROWS_T) != 0);
+                                (uint4*)d_out, (flags & ACX_DIST_ROWS_T) != 0, (const uint4*)d_mul, (const uint4*)d_add);
 }
 
 int acx_ntt_dist_step_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,

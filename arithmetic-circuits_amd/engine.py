@@ -114,11 +114,13 @@ class Context:
         check(self.lib.acx_qap_sub_o_dev(self._h, log_n, count, _ptr(sh), d_h, d_o))
 
     def ntt_dist_step_dev(self, d_in: int, d_out: int, log_n: int, log_r: int, world: int, rank: int, inverse: bool, step: int,
-                          shift: Optional[int] = None, rows_t: bool = False) -> None:
+                          shift: Optional[int] = None, rows_t: bool = False, d_mul: int = 0, d_add: int = 0) -> None:
         """One local step of the distributed four-step NTT (include/acx.h: COLS / ROWS / XCHG layouts); rows_t: the input of
-        an inverse step 0 is the transposed ROWS block (rows in ascending order), ACX_DIST_ROWS_T."""
+        an inverse step 0 is the transposed ROWS block (rows in ascending order), ACX_DIST_ROWS_T.  d_mul: the step transforms
+        d_in[i] * d_mul[i]; d_add: d_out[k] = X[k] + d_add[k] (acx_ntt_dist_step_fused_dev: the h(x) pipeline's fused forms)."""
         sh = ints_to_fr([shift]) if shift is not None else None
-        check(self.lib.acx_ntt_dist_step_ex_dev(self._h, log_n, log_r, world, rank, int(inverse), step, 1 if rows_t else 0, _ptr(sh), d_in, d_out))
+        check(self.lib.acx_ntt_dist_step_fused_dev(self._h, log_n, log_r, world, rank, int(inverse), step, 1 if rows_t else 0, _ptr(sh),
+                                                   d_in, d_mul or None, d_add or None, d_out))
 
 
 class R1CS:
@@ -235,6 +237,12 @@ class R1CS:
 
     def qap_columns_dev(self, matrix: int, wire_begin: int, wire_count: int, d_out: int, d_len: int = 0) -> None:
         check(self.ctx.lib.acx_qap_columns_dev(self._h, matrix, wire_begin, wire_count, d_out, d_len or None))
+
+    def dots_h_dev(self, d_witness: int, d_result: int, d_dots: int, h_log_n: int, shift: Optional[int] = None, row_offset: int = 0) -> None:
+        """verify_dev storing the dot products for h(x) over 2^h_log_n points on the coset shift * <omega> (None: the field's
+        generator): <A_i,w> / z, <B_i,w>, -<C_i,w> / z with z = shift^N - 1 (acx_r1cs_dots_h_dev)."""
+        sh = ints_to_fr([shift]) if shift is not None else None
+        check(self.ctx.lib.acx_r1cs_dots_h_dev(self._h, d_witness, row_offset, d_result, d_dots, h_log_n, _ptr(sh)))
 
     def verify_dev(self, d_witness: int, d_result: int, row_offset: int = 0, d_residuals: int = 0, d_dots: int = 0) -> None:
         check(self.ctx.lib.acx_r1cs_verify_dev(self._h, d_witness, row_offset, d_result, d_residuals or None, d_dots or None))

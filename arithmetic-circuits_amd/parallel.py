@@ -142,10 +142,12 @@ class LocalRows:
         """the (replicated) witness in whatever form verify() takes"""
         raise NotImplementedError
 
-    def verify(self, w, want_first: bool = False, dots: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def verify(self, w, want_first: bool = False, dots: Optional[torch.Tensor] = None, h_log_n: int = 0,
+               h_shift: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Local check on a prepared witness: (verdict = [violated rows, non-canonical flag], first = [smallest violated GLOBAL
         row or 2^62]) as int64 tensors, not yet reduced over the ranks; dots (3 * len(rows) elements) receives <A_i,w>, <B_i,w>,
-        <C_i,w> of the local rows in local order when given."""
+        <C_i,w> of the local rows in local order when given.  h_log_n != 0: the dots are stored FOR h(x) over 2^h_log_n points
+        (the global transform size): <A_i,w> / z, <B_i,w>, -<C_i,w> / z with z = h_shift^N - 1 (acx_r1cs_dots_h_dev)."""
         raise NotImplementedError
 
 
@@ -174,7 +176,7 @@ class HipLocalRows(LocalRows):
         ctx.dev_from_canonical(self.m, w.data_ptr(), w.data_ptr(), self._flag.data_ptr())
         return w
 
-    def verify(self, w: torch.Tensor, want_first: bool = False, dots: Optional[torch.Tensor] = None):
+    def verify(self, w: torch.Tensor, want_first: bool = False, dots: Optional[torch.Tensor] = None, h_log_n: int = 0, h_shift=None):
         none = 1 << 62
         res_vec = None
         # libacx launches on its own stream: order it after whatever the caller's stream still has in flight on `w` / `dots`
@@ -184,8 +186,12 @@ class HipLocalRows(LocalRows):
             self._res.copy_(torch.tensor([0, -1], dtype=torch.int64), non_blocking=False)
             if want_first and not self._monotone:
                 res_vec = torch.empty((self.rows.shape[0], 4), dtype=torch.int64, device=self._res.device)
-            self.r1cs.verify_dev(w.data_ptr(), self._res.data_ptr(), d_dots=dots.data_ptr() if dots is not None else 0,
-                                 d_residuals=res_vec.data_ptr() if res_vec is not None else 0)
+            if h_log_n and dots is not None and res_vec is None:
+                self.r1cs.dots_h_dev(w.data_ptr(), self._res.data_ptr(), dots.data_ptr(), h_log_n, h_shift)
+            else:
+                assert not h_log_n, "scaled dots come without the residual vector"
+                self.r1cs.verify_dev(w.data_ptr(), self._res.data_ptr(), d_dots=dots.data_ptr() if dots is not None else 0,
+                                     d_residuals=res_vec.data_ptr() if res_vec is not None else 0)
             verdict = torch.stack([self._res[0], self._flag[0].to(torch.int64)])
             first = torch.full((1,), none, dtype=torch.int64, device=self._res.device)
             if want_first and self._monotone:
@@ -274,9 +280,10 @@ class ShardedR1CS:
         """Local launch on a prepared (device-resident) witness; returns the (not yet reduced) verdict tensors."""
         return self.local.verify(w, want_first, dots)
 
-    def dots(self, w, out: torch.Tensor):
-        """<A_i,w>, <B_i,w>, <C_i,w> of the local rows into out (3 * rows elements), plus the local verdict."""
-        return self.local.verify(w, False, out)
+    def dots(self, w, out: torch.Tensor, h_log_n: int = 0, h_shift: Optional[int] = None):
+        """<A_i,w>, <B_i,w>, <C_i,w> of the local rows into out (3 * rows elements), plus the local verdict; h_log_n: stored for
+        h(x) over 2^h_log_n points on the coset h_shift * <omega> (LocalRows.verify)."""
+        return self.local.verify(w, False, out, h_log_n, h_shift)
 
     def _reduce(self, verdict: torch.Tensor, first: torch.Tensor, want_first: bool) -> Tuple[bool, int, int]:
         if self.world > 1:
@@ -297,8 +304,10 @@ class LocalOps:
     elements, shape (count, 4), in whatever element format the implementation uses."""
 
     def dist_step(self, src: torch.Tensor, dst: torch.Tensor, log_n: int, log_r: int, world: int, rank: int,
-                  inverse: bool, step: int, shift: Optional[int], rows_t: bool = False) -> None:
-        """rows_t (inverse step 0 only): src is the transposed ROWS block [k2][kl] (include/acx.h, ACX_DIST_ROWS_T)."""
+                  inverse: bool, step: int, shift: Optional[int], rows_t: bool = False,
+                  mul: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None) -> None:
+        """rows_t (inverse step 0 only): src is the transposed ROWS block [k2][kl] (include/acx.h, ACX_DIST_ROWS_T).
+        mul: the step transforms src[i] * mul[i]; add: dst[k] = X[k] + add[k] (acx_ntt_dist_step_fused_dev)."""
         raise NotImplementedError
 
     def pointwise_h(self, a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], out: torch.Tensor, log_n: int, shift: int) -> None:
@@ -327,9 +336,12 @@ class HipOps(LocalOps):
         if cur.cuda_stream != self._ext.cuda_stream:
             cur.wait_stream(self._ext)
 
-    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift, rows_t=False):
+    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift, rows_t=False, mul=None, add=None):
         assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()
-        self._fenced(lambda: self.ctx.ntt_dist_step_dev(src.data_ptr(), dst.data_ptr(), log_n, log_r, world, rank, inverse, step, shift, rows_t))
+        assert all(t is None or (t.is_cuda and t.is_contiguous()) for t in (mul, add))
+        self._fenced(lambda: self.ctx.ntt_dist_step_dev(src.data_ptr(), dst.data_ptr(), log_n, log_r, world, rank, inverse, step, shift, rows_t,
+                                                        d_mul=mul.data_ptr() if mul is not None else 0,
+                                                        d_add=add.data_ptr() if add is not None else 0))
 
     def pointwise_h(self, a, b, c, out, log_n, shift):
         self._fenced(lambda: self.ctx.qap_pointwise_dev(a.data_ptr(), b.data_ptr(), c.data_ptr() if c is not None else None,
@@ -417,13 +429,15 @@ class DistributedNTT:
             outer.wait_stream(ext)
         return fenced()
 
-    def begin(self, x: torch.Tensor, inverse: bool, shift: Optional[int] = None, slot: int = 0, rows_t: bool = False):
+    def begin(self, x: torch.Tensor, inverse: bool, shift: Optional[int] = None, slot: int = 0, rows_t: bool = False,
+              mul: Optional[torch.Tensor] = None):
         """First local step of one transform and the START of its all-to-all (src/QAP.hs:512-525's transform, sharded).
-        Returns a token for finish().  Transforms in flight at the same time need different slots (buffer pairs)."""
+        Returns a token for finish().  Transforms in flight at the same time need different slots (buffer pairs).
+        mul: the transform of the pointwise product x * mul (same layout), formed as the step loads its points."""
         assert x.shape == (self.local, 4) and x.is_contiguous()
         send, recv = self._buffers(x, slot)
         a = (self.log_n, self.log_r, self.world, self.rank, inverse)
-        self.ops.dist_step(x, send, *a, 0, shift, rows_t)
+        self.ops.dist_step(x, send, *a, 0, shift, rows_t, mul=mul)
         work, got = None, send
         if self._exchanges():
             # enqueued behind the local step on the current stream; with RCCL it returns at once and the xGMI links work while
@@ -432,14 +446,15 @@ class DistributedNTT:
             got = recv
         return (work, got, a, shift)
 
-    def finish(self, token, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Wait (stream-side) for the exchange, then the second local step."""
+    def finish(self, token, out: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Wait (stream-side) for the exchange, then the second local step.  add: a vector in the output's layout added
+        behind the step's closing multiplication."""
         work, got, a, shift = token
         if work is not None:
             work.wait()
         if out is None:
             out = torch.empty_like(got)
-        self.ops.dist_step(got, out, *a, 1, shift)
+        self.ops.dist_step(got, out, *a, 1, shift, add=add)
         return out
 
     def _run(self, x: torch.Tensor, out: Optional[torch.Tensor], inverse: bool, shift: Optional[int], rows_t: bool = False) -> torch.Tensor:
@@ -458,11 +473,13 @@ class DistributedQapH:
     """`verificationWitness` (src/QAP.hs:292-327, delta = 0) over all GPUs: h = (L*R - O) / (x^N - 1).
 
     Rows are owned block-cyclically (ShardedR1CS.from_cyclic), so the residual kernel's <A_i,w>, <B_i,w>, <C_i,w>
-    ARE the ROWS layout of three evaluation vectors.  Then 3 inverse transforms (-> coefficients, COLS), 2 forward
-    coset transforms (L and R -> ROWS), the pointwise product / z, 1 inverse coset transform and, in coefficient form,
-    minus O / z: h's coefficients in COLS layout (rank g holds h[i1*C + g*C/W + i2l]).  O(x) never needs its coset
-    evaluations -- the transforms are linear and icoset(coset(O)) = O -- so there are six all-to-alls, not seven, and
-    one verdict all-reduce."""
+    ARE the ROWS layout of three evaluation vectors -- stored as <A_i,w> / z, <B_i,w>, -<C_i,w> / z (z = g^N - 1 on the
+    coset): the factors ride on the residual launch's stores.  Then 3 inverse transforms (-> coefficients, COLS), 2 forward
+    coset transforms (L / z and R -> ROWS) and 1 inverse coset transform that takes their PRODUCT as its first step loads
+    the points and adds -O / z (coefficient form, COLS) behind the closing multiplication of its second step: h's
+    coefficients in COLS layout (rank g holds h[i1*C + g*C/W + i2l]).  O(x) never needs its coset evaluations -- the
+    transforms are linear and icoset(coset(O)) = O -- so there are six all-to-alls, not seven, one verdict all-reduce, and
+    no elementwise pass outside the transforms (DESIGN.md section 4 "h(x) in round 3")."""
 
     def __init__(self, sharded: ShardedR1CS, ntt: DistributedNTT, generator: int):
         assert sharded.rows.shape[0] == ntt.local
@@ -479,7 +496,7 @@ class DistributedQapH:
             self._bufs = (torch.empty((3 * L, 4), dtype=torch.int64, device=dev),
                           torch.empty((3 * L, 4), dtype=torch.int64, device=dev))
         dots, tmp = self._bufs
-        verdict, first = self.sharded.dots(w, dots)                       # rows of padding give 0
+        verdict, first = self.sharded.dots(w, dots, h_log_n=nt.log_n, h_shift=self.g)     # rows of padding give 0
         part = lambda t, k: t[k * L:(k + 1) * L]
         # Software pipeline over the three vectors: the exchange of vector k runs (on RCCL's stream) under the local
         # steps of vector k+1, and a vector's forward transform starts as soon as its inverse one is complete -- of
@@ -494,8 +511,7 @@ class DistributedQapH:
                     fwd.append(nt.begin(part(tmp, k), False, self.g, slot=k))
             for k in range(2):
                 nt.finish(fwd[k], out=part(dots, k))
-            nt.ops.pointwise_h(dots[:L], dots[L:2 * L], None, tmp[:L], nt.log_n, self.g)
-            h = nt.finish(nt.begin(tmp[:L], True, self.g, slot=0), out=tmp[L:2 * L])
-            nt.ops.sub_o(h, part(tmp, 2), nt.log_n, self.g)            # O's coefficients are in COLS ownership, like h
+            # (L / z) * R on the way in, -O / z on the way out (O's coefficients are in COLS ownership, like h)
+            h = nt.finish(nt.begin(dots[:L], True, self.g, slot=0, mul=dots[L:2 * L]), out=tmp[:L], add=part(tmp, 2))
         ok, _, _ = self.sharded._reduce(verdict, first, False)
         return h, ok

@@ -4,11 +4,13 @@
 //
 //   rows          every rank loads ONLY its rows, block-cyclic and in ascending order: local row [k2][kl] = global row
 //                 (rank*R/W + kl) + k2*R, so the residual kernel's <A_i,w>, <B_i,w>, <C_i,w> ARE three evaluation vectors in the
-//                 transposed ROWS layout, which the first inverse steps read through their strides (ACX_DIST_ROWS_T)
-//   3 inverse     acx_ntt_dist_step_dev(step 0) -> ncclAllToAll -> (step 1): coefficients of L, R, O in COLS ownership
-//   2 coset       L and R only: O(x) enters the quotient in coefficient form (include/acx.h, acx_qap_sub_o_dev)
-//   pointwise     acx_qap_pointwise_dev(.., d_c = NULL, ..)
-//   1 inverse coset, then acx_qap_sub_o_dev: h in COLS ownership (rank g holds h[i1*C + g*C/W + i2l])
+//                 transposed ROWS layout, which the first inverse steps read through their strides (ACX_DIST_ROWS_T);
+//                 acx_r1cs_dots_h_dev stores them as <A_i,w> / z, <B_i,w>, -<C_i,w> / z (z = g^N - 1 on the coset)
+//   3 inverse     acx_ntt_dist_step_dev(step 0) -> ncclAllToAll -> (step 1): coefficients of L / z, R, -O / z in COLS ownership
+//   2 coset       L / z and R only: O(x) enters the quotient in coefficient form
+//   1 inverse coset through acx_ntt_dist_step_fused_dev: its first step transforms the PRODUCT (L / z) * R as it loads the
+//                 points, its second step adds -O / z behind the closing multiplication: h in COLS ownership (rank g holds
+//                 h[i1*C + g*C/W + i2l]) with no elementwise pass outside the transforms
 //   verdict       ONE ncclAllReduce of the violated-row counts
 // Six all-to-alls per h(x).  Every rank also computes h(x) of the whole system on its own GPU (acx_qap_h) and compares
 // its block: the distributed four-step transforms against the single-GPU pass kernels.
@@ -104,10 +106,10 @@ int main() {
     ACXCHECK(load(ctx, rows_of(mine), L, m, &r_local));
     ACXCHECK(load(ctx, rows_of(all), N, m, &r_full));
 
-    void *d_w, *dots, *coef, *send, *recv, *tmp, *h;
+    void *d_w, *dots, *coef, *send, *recv, *h;
     HIPCHECK(hipMalloc(&d_w, m * 32));
     for (void** p : {&dots, &coef}) HIPCHECK(hipMalloc(p, 3 * L * 32));
-    for (void** p : {&send, &recv, &tmp, &h}) HIPCHECK(hipMalloc(p, L * 32));
+    for (void** p : {&send, &recv, &h}) HIPCHECK(hipMalloc(p, L * 32));
     uint64_t* d_res;
     HIPCHECK(hipMalloc((void**)&d_res, 16));
     acx_fr g = fr_u64(5);                                                    // coset generator: 5^N != 1 in BN254 Fr
@@ -133,12 +135,13 @@ int main() {
         ACXCHECK(acx_dev_from_canonical(ctx, m, d_w, d_w, nullptr));
         const uint64_t init[2] = {0, ~0ull};
         HIPCHECK(hipMemcpyAsync(d_res, init, 16, hipMemcpyHostToDevice, stream));
-        ACXCHECK(acx_r1cs_verify_dev(r_local, d_w, 0, d_res, nullptr, dots));               // dots: transposed ROWS layout, three vectors
+        ACXCHECK(acx_r1cs_dots_h_dev(r_local, d_w, 0, d_res, dots, log_n, &g));            // dots: transposed ROWS layout, three vectors, 1/z and -1/z riding on them
         for (uint64_t k = 0; k < 3; ++k) if (transform(1, nullptr, at(dots, k), at(coef, k), ACX_DIST_ROWS_T)) return 1;      // -> coefficients (COLS)
         for (uint64_t k = 0; k < 2; ++k) if (transform(0, &g, at(coef, k), at(dots, k))) return 1;           // L, R on the coset (ROWS)
-        ACXCHECK(acx_qap_pointwise_dev(ctx, log_n, L, &g, at(dots, 0), at(dots, 1), nullptr, tmp));
-        if (transform(1, &g, tmp, h)) return 1;                                                               // -> COLS
-        ACXCHECK(acx_qap_sub_o_dev(ctx, log_n, L, &g, h, at(coef, 2)));
+        // the last transform: (L / z) * R on the way in, -O / z on the way out -> h (COLS)
+        ACXCHECK(acx_ntt_dist_step_fused_dev(ctx, log_n, log_r, world, rank, 1, 0, 0, &g, at(dots, 0), at(dots, 1), nullptr, send));
+        if (exchange(send, recv)) return 1;
+        ACXCHECK(acx_ntt_dist_step_fused_dev(ctx, log_n, log_r, world, rank, 1, 1, 0, &g, recv, nullptr, at(coef, 2), h));
         NCCLCHECK(ncclAllReduce(d_res, d_res, 1, ncclUint64, ncclSum, comm, stream));                         // the verdict
         uint64_t res[2];
         HIPCHECK(hipMemcpyAsync(res, d_res, 16, hipMemcpyDeviceToHost, stream));

@@ -301,6 +301,21 @@ int acx_ntt_dist_step_dev(acx_ctx* ctx, uint32_t log_n, uint32_t log_r, uint32_t
 enum { ACX_DIST_ROWS_T = 1 };
 int acx_ntt_dist_step_ex_dev(acx_ctx* ctx, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse,
                              int step, uint32_t flags, const acx_fr* shift, const void* d_in, void* d_out);
+/* The two fused forms the h(x) pipeline uses (src/QAP.hs:292-327; DESIGN.md section 4 "h(x) in round 3"):
+ *   d_mul != NULL: the step transforms the POINTWISE PRODUCT d_in[i] * d_mul[i] (same layout) -- L * R on the coset is formed as
+ *                  the points are loaded, no product vector exists (not on step 0 of a forward coset transform);
+ *   d_add != NULL: d_out[k] = X[k] + d_add[k] (the layout of d_out) -- the coefficient-domain -O/z joins behind the closing
+ *                  multiplication of the last step.
+ * Both NULL: acx_ntt_dist_step_ex_dev. */
+int acx_ntt_dist_step_fused_dev(acx_ctx* ctx, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse,
+                                int step, uint32_t flags, const acx_fr* shift, const void* d_in, const void* d_mul,
+                                const void* d_add, void* d_out);
+/* acx_r1cs_verify_dev storing the dot products FOR h(x) over a transform of 2^h_log_n points (the GLOBAL size: a rank's own
+ * system has N / world rows): <A_i,w> is stored times 1/z and <C_i,w> times -1/z, z = shift^N - 1 (shift = the coset the
+ * host's transforms use; NULL = the field's generator, which acx_qap_h uses), so that (L/z) R + (-O/z) needs no pointwise
+ * pass and no scaled subtraction later; the verdict comes from the plain values.  d_dots: 3 * 2^(log_n of r) dev elements. */
+int acx_r1cs_dots_h_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset, uint64_t* d_result, void* d_dots,
+                        uint32_t h_log_n, const acx_fr* shift);
 
 /* The pointwise step of h(x) on a coset (src/QAP.hs:325-327 in evaluation form): out[i] = (a[i]*b[i] - c[i]) /
  * (shift^N - 1), N = 2^log_n, on `count` dev elements (any slice of the evaluation vectors: the operation is

@@ -38,7 +38,7 @@ class OracleOps(par.LocalOps):
     def _ntt(self, vals, log_len, inverse):
         return limbs_to_ints(self.orc.ntt(ints_to_limbs(vals), log_len, inverse=inverse))
 
-    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift, rows_t=False):
+    def dist_step(self, src, dst, log_n, log_r, world, rank, inverse, step, shift, rows_t=False, mul=None, add=None):
         p = self.orc.p
         N, R = 1 << log_n, 1 << log_r
         C = N // R
@@ -47,6 +47,8 @@ class OracleOps(par.LocalOps):
         if inverse:
             w = pow(w, -1, p)
         a = _ints(src)
+        if mul is not None:                      # the contract of acx_ntt_dist_step_fused_dev: product on the way in
+            a = [x * y % p for x, y in zip(a, _ints(mul))]
         if rows_t:                               # [k2][kl] -> [kl][k2]: the contract of ACX_DIST_ROWS_T
             assert inverse and step == 0
             a = [a[k2 * rw + kl] for kl in range(rw) for k2 in range(C)]
@@ -78,6 +80,8 @@ class OracleOps(par.LocalOps):
                     si = pow(shift, -1, p)
                     x = [v * pow(si, i1 * C + i2, p) % p for i1, v in enumerate(x)]
                 out[i2l * R:(i2l + 1) * R] = x
+        if add is not None:                      # ... and a vector of the output's layout added on the way out
+            out = [(x + y) % p for x, y in zip(out, _ints(add))]
         dst.copy_(_tensor(out))
 
     def pointwise_h(self, a, b, c, out, log_n, shift):
@@ -112,15 +116,18 @@ def main():
         def prepare(self, witness):
             return witness
 
-        def verify(self, wit, want_first=False, dots=None):
+        def verify(self, wit, want_first=False, dots=None, h_log_n=0, h_shift=None):
             res, nbad, _ = orc.r1cs_residuals(len(self.lm[0][0]) - 1, self.m, *self.lm, wit)
             badrows = self.rows[res.any(axis=1)]
             if dots is not None:
                 wi = limbs_to_ints(wit)
                 vals = []
-                for rowptr, col, val in self.lm:
+                # the contract of acx_r1cs_dots_h_dev: <A_i,w> / z, <B_i,w>, -<C_i,w> / z with z = shift^N - 1
+                zinv = pow(pow(h_shift, 1 << h_log_n, p) - 1, -1, p) if h_log_n else None
+                for k, (rowptr, col, val) in enumerate(self.lm):
                     v = limbs_to_ints(val)
-                    vals += [sum(v[e] * wi[int(col[e])] for e in range(int(rowptr[i]), int(rowptr[i + 1]))) % p
+                    f = 1 if zinv is None else (zinv, 1, p - zinv)[k]
+                    vals += [sum(v[e] * wi[int(col[e])] for e in range(int(rowptr[i]), int(rowptr[i + 1]))) * f % p
                              for i in range(len(rowptr) - 1)]
                 dots.copy_(_tensor(vals))
             return (torch.tensor([nbad, 0], dtype=torch.int64),

@@ -5,9 +5,11 @@ four-step transform take (world, rank) as plain arguments, the rank's block-cycl
 row source, and the all-to-all moves a known number of bytes.  Prints microseconds per local step (HIP events on
 libacx's stream) and the exchange volume, from which the 8-GPU time of one distributed h(x) follows:
 
-    t = residual_dots + 3 * (inv0t + inv1) + 2 * (fwd0c + fwd1) + pointwise + (inv0 + inv1c) + sub_o + 6 * exchange + all-reduce
+    t = residual_dots_h + 3 * (inv0t + inv1) + 2 * (fwd0c + fwd1) + (inv0m + inv1ca) + 6 * exchange + all-reduce
 (six transforms: O(x) stays in coefficient form; the rank's rows are loaded in ascending order, so the three
-inverse transforms of the dots start from the transposed ROWS block: inv0t)
+inverse transforms of the dots start from the transposed ROWS block: inv0t; 1/z and -1/z ride on the stored dots, the last
+transform takes the product L * R on the way in (inv0m) and adds -O/z on the way out (inv1ca): no elementwise pass is left.
+Round 2's sequence -- residual_dots, pointwise, inv0 + inv1c, sub_o -- is printed beside it.)
 
 python tools/dist_budget.py [--world 8] [--logn 24]   (run under rocprofv3 --kernel-trace for the kernel view)"""
 import argparse
@@ -54,10 +56,12 @@ def main():
     ctx.dev_from_canonical(L, x.data_ptr(), x.data_ptr())
     y = torch.empty_like(x)
     t = {}
-    for name, inv, step, shift, rows_t in (("fwd0", False, 0, None, False), ("fwd0c", False, 0, g, False), ("fwd1", False, 1, None, False),
-                                           ("inv0", True, 0, None, False), ("inv0t", True, 0, None, True), ("inv1", True, 1, None, False),
-                                           ("inv1c", True, 1, g, False)):
-        t[name] = timed(stream, lambda: ctx.ntt_dist_step_dev(x.data_ptr(), y.data_ptr(), ln, lr, W, 0, inv, step, shift, rows_t))
+    x2 = x.clone()
+    for name, inv, step, shift, rows_t, mul, add in (("fwd0", False, 0, None, False, 0, 0), ("fwd0c", False, 0, g, False, 0, 0), ("fwd1", False, 1, None, False, 0, 0),
+                                                     ("inv0", True, 0, None, False, 0, 0), ("inv0t", True, 0, None, True, 0, 0), ("inv1", True, 1, None, False, 0, 0),
+                                                     ("inv1c", True, 1, g, False, 0, 0), ("inv0m", True, 0, g, False, x2.data_ptr(), 0),
+                                                     ("inv1ca", True, 1, g, False, 0, x2.data_ptr())):
+        t[name] = timed(stream, lambda: ctx.ntt_dist_step_dev(x.data_ptr(), y.data_ptr(), ln, lr, W, 0, inv, step, shift, rows_t, d_mul=mul, d_add=add))
     # rank 0's rows of the 2^logn-constraint block system, block-cyclic ownership
     bs = synth.BlockSystem(synth.mulgraph(1 << 16, seed=0xAC4, field=a.field), (1 << ln) >> 16)
     rows = par.cyclic_rows(ln, lr, W, 0, ascending=True)          # ascending order: the dots come out as the transposed ROWS block
@@ -70,12 +74,14 @@ def main():
     res = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     t["residual_dots"] = timed(stream, lambda: r.verify_dev(dw.data_ptr(), res.data_ptr(), d_dots=dots.data_ptr()))
+    t["residual_dots_h"] = timed(stream, lambda: r.dots_h_dev(dw.data_ptr(), res.data_ptr(), dots.data_ptr(), ln))
     t["residual_only"] = timed(stream, lambda: r.verify_dev(dw.data_ptr(), res.data_ptr()))
     assert int(res[0]) == 0
     t["pointwise"] = timed(stream, lambda: ctx.qap_pointwise_dev(dots.data_ptr(), dots[L:].data_ptr(), None, y.data_ptr(), L, ln, g))
     t["sub_o"] = timed(stream, lambda: ctx.qap_sub_o_dev(y.data_ptr(), dots[2 * L:].data_ptr(), L, ln, g))
     xbytes = L * 32 * (W - 1) // W
-    local = t["residual_dots"] + 3 * (t["inv0t"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["pointwise"] + t["inv0"] + t["inv1c"] + t["sub_o"]
+    local_r2 = t["residual_dots"] + 3 * (t["inv0t"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["pointwise"] + t["inv0"] + t["inv1c"] + t["sub_o"]
+    local = t["residual_dots_h"] + 3 * (t["inv0t"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["inv0m"] + t["inv1ca"]
     print(f"rank-local budget of a {W}-rank job, N = 2^{ln} = 2^{lr} x 2^{ln - lr}, {a.field} Fr, {L} elements per rank (us):")
     for k, v in t.items():
         print(f"  {k:14s} {v:10.1f}")
@@ -84,6 +90,7 @@ def main():
         ex = xbytes / (7 * bw) * 1e6 if W > 1 else 0.0
         print(f"  h(x) per rank: local {local:9.1f} us + 6 exchanges at {bw / 1e9:.0f} GB/s/link x 7 links {6 * ex:8.1f} us = {local + 6 * ex:9.1f} us"
               f" -> {(1 << ln) / (local + 6 * ex) * 1e6:.3e} constraints/s over {W} GPUs")
+    print(f"  (round 2's sequence with the two elementwise kernels: local {local_r2:9.1f} us)")
     dnt = t["fwd0"] + t["fwd1"]
     print(f"  one forward transform per rank: {dnt:.1f} us local (+ exchange)")
 
