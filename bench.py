@@ -43,6 +43,20 @@ def to_dev(ctx, arr):
     return t
 
 
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask, cut by the cgroup's CPU quota (cpu.max = "quota period") when there is
+    one -- on the GPU boxes 256 hardware threads are visible under a quota of 16 CPUs, and 256 busy threads are then throttled
+    below what 16 deliver (tools/cpu_scaling.py)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sample, field="bn254", budget_s=12.0):
     """The CPU restatement (oracle/acx_oracle.c, "port") timed on this host's cores on a bounded
     sample of the same workload: one 2^16-constraint system verified `repeat` times per call
@@ -50,7 +64,7 @@ def cpu_baseline(sample, field="bn254", budget_s=12.0):
     from oracle.c_oracle import COracle
     orc = COracle(field)
     mats, w, n, m = sample
-    threads = os.cpu_count() or 1
+    threads = effective_cpus()
     repeat = 64
     orc.r1cs_residuals(n, m, *mats, w, want_residuals=False, nthreads=threads, repeat=2)   # warm-up
     calls, t0 = 0, time.perf_counter()
@@ -63,7 +77,8 @@ def cpu_baseline(sample, field="bn254", budget_s=12.0):
             break
     out = {"value": n * repeat * calls / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
            "sample": f"{calls * repeat} x verifyAssignment of one 2^{n.bit_length() - 1}-constraint system "
-                     f"(oracle/acx_oracle.c, {threads} pthreads, {dt:.1f} s)"}
+                     f"(oracle/acx_oracle.c, {threads} pthreads = the CPUs this process may use: {os.cpu_count()} hardware threads visible, "
+                     f"cgroup quota applied; {dt:.1f} s)"}
     out["reference_algorithm"] = cpu_reference_algorithm(orc, field)
     return out
 
@@ -153,7 +168,7 @@ def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=40, prewarm=0.25, batch
     x_host = synth.random_fr(n, 5, 1, field)
     x = to_dev(ctx, x_host)
     ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=True)
-    parity = bool(np.array_equal(_from_dev(ctx, x, n), orc.ntt(x_host, log_n, inverse=True, nthreads=os.cpu_count() or 1)))
+    parity = bool(np.array_equal(_from_dev(ctx, x, n), orc.ntt(x_host, log_n, inverse=True, nthreads=effective_cpus())))
     ctx.ntt_dev(x.data_ptr(), log_n, 1, inverse=False)
     parity = parity and bool(np.array_equal(_from_dev(ctx, x, n), x_host))
     flip = [False]
@@ -201,7 +216,7 @@ def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
     r.qap_h_dev(dw.data_ptr(), dh.data_ptr(), res.data_ptr())
     ctx.sync()
     got = _from_dev(ctx, dh, n + 1)
-    want, ok = orc.qap_h(n, r.m, log_n, *mats, w, nthreads=os.cpu_count() or 1)
+    want, ok = orc.qap_h(n, r.m, log_n, *mats, w, nthreads=effective_cpus())
     parity = bool(ok and int(res[0]) == 0 and np.array_equal(got, want))
     us = _timed(stream, lambda: r.qap_h_dev(dw.data_ptr(), dh.data_ptr(), res.data_ptr()), reps, prewarm)
     b_r1cs, nnz, _ = algorithmic_bytes(mats, n)
@@ -228,7 +243,7 @@ def bench_small_coeff(ctx, stream, field="bn254", copies=32, log_n=16, reps=50, 
             mats = s.rows()
             w2 = w.copy()
             w2[[3, 1500, r.m - 2], 0] ^= np.uint64(1)
-            want, nbad, first = orc.r1cs_residuals(n, r.m, *mats, w2, nthreads=os.cpu_count() or 1)
+            want, nbad, first = orc.r1cs_residuals(n, r.m, *mats, w2, nthreads=effective_cpus())
             parity = bool(np.array_equal(r.residuals(w2), want) and r.verify(w2) == (False, nbad, first) and nbad > 0)
             fmt = r.format()
             alg = algorithmic_bytes(mats, n)[0] * copies
@@ -286,7 +301,7 @@ def bench_distributed(ctx, a, world, rank, dist):
     d16 = par.DistributedNTT(ln, ops, log_r=8, force_collective=force, collectives=coll)
     x16 = synth.random_fr(1 << ln, 31, 1, a.field)
     got = _from_dev(ctx, d16.forward(to_dev(ctx, x16[d16.cols_indices()])), d16.local)
-    parity = bool(np.array_equal(got, orc.ntt(x16, ln, nthreads=os.cpu_count() or 1)[d16.rows_indices()]))
+    parity = bool(np.array_equal(got, orc.ntt(x16, ln, nthreads=effective_cpus())[d16.rows_indices()]))
     # --- 2^24 transform
     ln, lr = a.dist_logn, a.dist_logn // 2
     d = par.DistributedNTT(ln, ops, log_r=lr, force_collective=force, collectives=coll)
@@ -388,7 +403,7 @@ def main_mgpu(a, devices):
     orc = COracle(a.field)
     wb = w.copy()
     wb[bs.wire(a.copies * W - 1, 77), 0] ^= np.uint64(1)
-    _, nbad0, first0 = orc.r1cs_residuals(n0, bs.m0, *bs.mats, np.concatenate([wb[:1], wb[-(bs.m0 - 1):]]), nthreads=os.cpu_count() or 1)
+    _, nbad0, first0 = orc.r1cs_residuals(n0, bs.m0, *bs.mats, np.concatenate([wb[:1], wb[-(bs.m0 - 1):]]), nthreads=effective_cpus())
     got = mr.verify(wb)
     parity = bool(nbad0 > 0 and got == (False, nbad0, (a.copies * W - 1) * n0 + first0))
     out = {
@@ -603,7 +618,7 @@ def main():
         mats0, w0, n0, m0 = sample
         w0b = w0.copy()
         w0b[77, 0] ^= np.uint64(1)
-        want_res, want_bad, want_first = COracle(a.field).r1cs_residuals(n0, m0, *mats0, w0b, nthreads=os.cpu_count() or 1)
+        want_res, want_bad, want_first = COracle(a.field).r1cs_residuals(n0, m0, *mats0, w0b, nthreads=effective_cpus())
         parity_residuals = bool(want_bad > 0 and int(neg[0]) == want_bad and np.array_equal(systems[0].residuals(w0b), want_res)
                                 and systems[0].verify(w0b) == (False, want_bad, want_first))
         assert parity_residuals, "residual vector of the corrupted system differs from the oracle's"
