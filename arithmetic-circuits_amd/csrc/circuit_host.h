@@ -9,6 +9,8 @@
 //   gateToGenQAP              src/QAP.hs:366-474   (row contents: SURVEY.md Appendix A.2)
 //   qapSetToMap numbering     src/QAP.hs:605-620
 #pragma once
+#include <cstdio>
+#include <cstring>
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -32,8 +34,26 @@ struct SparseRow {
 
 // Worker threads for the host-side loops over gates / scalars (row generation is the reference's
 // arithCircuitToGenQAP, src/QAP.hs:530-539).  ACX_HOST_THREADS overrides the count.
+// CPUs this process may really use: the hardware threads, cut by a cgroup CPU quota when there is one (cpu.max = "quota
+// period"; the GPU boxes show 256 threads under a quota of 16: more busy threads than that are only throttled)
+inline unsigned usable_cpus() {
+    static const unsigned cached = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            unsigned long long period = 0;
+            if (std::fscanf(f, "%31s %llu", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+                const unsigned long long quota = std::strtoull(q, nullptr, 10);
+                if (quota > 0) n = (unsigned)std::min<unsigned long long>(n, std::max<unsigned long long>(1, (quota + period / 2) / period));
+            }
+            std::fclose(f);
+        }
+        return n;
+    }();
+    return cached;
+}
 inline unsigned host_threads(uint64_t items, uint64_t grain) {
-    unsigned t = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 64u, (unsigned)(items / grain + 1)});
+    unsigned t = std::min<unsigned>({usable_cpus(), 64u, (unsigned)(items / grain + 1)});
     if (const char* e = std::getenv("ACX_HOST_THREADS")) t = (unsigned)std::min(256, std::max(1, std::atoi(e)));
     return t;
 }
