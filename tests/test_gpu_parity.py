@@ -454,6 +454,56 @@ def test_hip_ops_distributed_layer_world1(request, acx, field):
     assert not qh.run(_dev(ctx, bad))[1]
 
 
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+def test_fused_distributed_steps_product_on_load_sum_on_store(request, acx, field):
+    """acx_ntt_dist_step_fused_dev by itself (include/acx.h): an inverse coset transform over the two local steps at world
+    size 1 whose first step takes the pointwise PRODUCT of two vectors as it loads the points (d_mul) and whose second step
+    adds a vector of the output's layout behind its closing multiplication (d_add) equals, element by element,
+    icoset(x * m) + a computed with the C oracle -- even and odd digits; and acx_r1cs_dots_h_dev stores <A_i,w> / z,
+    <B_i,w>, -<C_i,w> / z for z = shift^N - 1 of the GLOBAL size it is told."""
+    import torch
+    ctx, orc = _ctx(request, field), _orc(request, field)
+    par = __import__("importlib").import_module("arithmetic-circuits_amd.parallel")
+    synth = __import__("importlib").import_module("arithmetic-circuits_amd.synth")
+    p, g = ctx.p, orc.generator
+    from oracle.c_oracle import ints_to_limbs, limbs_to_ints
+    for log_n, log_r in ((12, 6), (13, 6), (15, 8)):
+        N = 1 << log_n
+        d = par.DistributedNTT(log_n, par.HipOps(ctx), log_r=log_r)
+        x, m, a = (synth.random_fr(N, 40 + k, log_n, field) for k in range(3))
+        prod = ints_to_limbs([u * v % p for u, v in zip(limbs_to_ints(x), limbs_to_ints(m))])
+        want = limbs_to_ints(orc.ntt(prod, log_n, inverse=True, shift=g, nthreads=8))
+        want = ints_to_limbs([(u + v) % p for u, v in zip(want, limbs_to_ints(a))])
+        xr, mr, ac = _dev(ctx, x[d.rows_indices()]), _dev(ctx, m[d.rows_indices()]), _dev(ctx, a[d.cols_indices()])
+        xchg, out = torch.empty_like(xr), torch.empty_like(xr)
+        torch.cuda.synchronize()
+        ctx.ntt_dist_step_dev(xr.data_ptr(), xchg.data_ptr(), log_n, log_r, 1, 0, True, 0, g, d_mul=mr.data_ptr())
+        ctx.ntt_dist_step_dev(xchg.data_ptr(), out.data_ptr(), log_n, log_r, 1, 0, True, 1, g, d_add=ac.data_ptr())
+        assert np.array_equal(_canon(ctx, out), want[d.cols_indices()]), (log_n, log_r)
+        with pytest.raises(acx.AcxError):                                    # no product on load of a forward coset step 0
+            ctx.ntt_dist_step_dev(xr.data_ptr(), xchg.data_ptr(), log_n, log_r, 1, 0, False, 0, g, d_mul=mr.data_ptr())
+        with pytest.raises(acx.AcxError):                                    # out of place only
+            ctx.ntt_dist_step_dev(xchg.data_ptr(), out.data_ptr(), log_n, log_r, 1, 0, True, 1, g, d_add=out.data_ptr())
+    # the dots stored for h(x) of a LARGER transform than the local system's own size
+    s = synth.mulgraph(700, n_in=8, window=64, seed=9, field=field)
+    mats, w = s.rows(), s.witness()
+    r = s.circuit.to_r1cs(ctx)
+    Nl = 1 << r.log_n
+    dw = _dev(ctx, w)
+    res = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
+    plain = torch.zeros((3 * Nl, 4), dtype=torch.int64, device="cuda")
+    scaled = torch.zeros((3 * Nl, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    r.verify_dev(dw.data_ptr(), res.data_ptr(), d_dots=plain.data_ptr())
+    h_log_n, shift = 17, 11
+    r.dots_h_dev(dw.data_ptr(), res.data_ptr(), scaled.data_ptr(), h_log_n, shift)
+    assert int(res[0].item()) == 0
+    zinv = pow(pow(shift, 1 << h_log_n, p) - 1, -1, p)
+    pl, sc = limbs_to_ints(_canon(ctx, plain)), limbs_to_ints(_canon(ctx, scaled))
+    for k, f in enumerate((zinv, 1, p - zinv)):
+        assert sc[k * Nl: k * Nl + 700] == [v * f % p for v in pl[k * Nl: k * Nl + 700]], k
+
+
 def test_distributed_h_2_24_block_system_world1(request, acx):
     """configs[3]'s constraint system (2^24 constraints = 256 block-diagonal 2^16 mulgraph systems) through the
     distributed pipeline at world size 1: rank-local row marshalling in block-cyclic (ascending) order, residual dots written as
