@@ -57,6 +57,35 @@ def effective_cpus():
     return n
 
 
+def measure_traffic_live(a, timeout_s=240):
+    """HBM bytes the headline kernel fetches per launch, measured NOW: this script re-runs its batched launches (only those:
+    --only-steps) as a child under `rocprofv3 --pmc FETCH_SIZE` -- a counter pass of its own, no tracing beside it, as
+    MI355X_MICROARCH.md prescribes -- and reads the per-dispatch counter values from the profiler's database.  FETCH_SIZE
+    counts KiB and, on gfx950, half of what wide coalesced reads move (calibrated on a copy kernel, tools/prof.py): bytes =
+    value * 1024 * 2.  Returns (bytes per launch, launches averaged) or None when the profiler is missing or fails."""
+    import glob, shutil, sqlite3, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    out = tempfile.mkdtemp(prefix="acx_pmc_", dir="/tmp")
+    cmd = [sys.executable, os.path.abspath(__file__), "--only-steps", "--no-cpu", "--no-ntt", "--no-pmc", "--sustain", "0", "--steps", "20",
+           "--warmup", "2", "--prewarm", "0.05", "--field", a.field, "--copies", str(a.copies), "--logn", str(a.logn)]
+    try:
+        subprocess.call(["rocprofv3", "--pmc", "FETCH_SIZE", "-d", out, "-o", "fetch", "--"] + cmd, stdout=subprocess.DEVNULL,
+                        stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=timeout_s)
+        best = None
+        for db in glob.glob(os.path.join(out, "**", "*.db"), recursive=True):
+            cur = sqlite3.connect(db).cursor()
+            for name, v, cnt in cur.execute("select kernel_name, avg(value), count(*) from counters_collection "
+                                            "where counter_name = 'FETCH_SIZE' group by kernel_name"):
+                if "k_r1cs_sell_split" in name and (best is None or cnt > best[1]):
+                    best = (v * 1024.0 * 2.0, cnt)
+        return best
+    except Exception:                                  # a profiler problem must not cost the line
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def cpu_baseline(sample, field="bn254", budget_s=12.0):
     """The CPU restatement (oracle/acx_oracle.c, "port") timed on this host's cores on a bounded
     sample of the same workload: one 2^16-constraint system verified `repeat` times per call
@@ -462,6 +491,8 @@ def main():
     ap.add_argument("--dist-logn", type=int, default=24, help="size of the distributed NTT / h(x) job timed when N > 1 or --force-dist")
     ap.add_argument("--no-dist-pipeline", action="store_true", help="skip the distributed NTT / h(x) measurements of a multi-rank run")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE pass (roofline.traffic then comes from profiles/r03_traffic.json, flagged)")
+    ap.add_argument("--only-steps", action="store_true", help="internal: nothing but the batched launches (the child of the PMC pass)")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--launcher", default="auto", choices=["auto", "ranks", "mgpu"],
                     help="ranks: one process per GPU (torch.distributed.run, what the driver uses); mgpu: ONE process, all GPUs "
@@ -613,7 +644,7 @@ def main():
     # ... and not merely "something was caught": system 0's whole residual vector, violated-row count and first violated
     # row under that corrupted witness against the CPU oracle, and the batched launch's count against the oracle's
     parity_residuals = None
-    if rank == 0:
+    if rank == 0 and not a.only_steps:
         from oracle.c_oracle import COracle
         mats0, w0, n0, m0 = sample
         w0b = w0.copy()
@@ -625,7 +656,7 @@ def main():
 
     # for reference: ONE 2^16-constraint system per launch (configs[1] taken literally; cache resident)
     single_us = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.only_steps:
         with torch.cuda.stream(stream):
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(5):
@@ -639,7 +670,7 @@ def main():
     # "also report the cache-resident number, labelled" -- the SAME system `copies` times per launch (each
     # against its own witness): its 16 MB of constraint stream stay in L2 / Infinity Cache, so this is NOT an HBM figure
     resident_us = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.only_steps:
         res_r = torch.tensor([0, -1], dtype=torch.int64, device="cuda")          # one {n_bad, first_bad} slot per batch
         rb = acx.Batch(ctx, [systems[0]] * a.copies, [witnesses[0].data_ptr()] * a.copies, res_r.data_ptr())
         with torch.cuda.stream(stream):
@@ -696,9 +727,24 @@ def main():
                                 "us_per_step_median": bs[len(bs) // 2], "us_per_step_min": bs[0], "us_per_step_max": bs[-1],
                                 "frac_median": bytes_per_launch / bs[len(bs) // 2] * 1e-3 / HBM_PEAK_GBS,
                                 "note": "kernel times at the sustained clock (0.25 s untimed pre-run before the timed region)"}
+        live = None
+        if world == 1 and not a.no_pmc and not a.only_steps:
+            live = measure_traffic_live(a)
+        if live is not None:
+            # HBM bytes of the headline kernel measured in THIS run: a rocprofv3 --pmc FETCH_SIZE pass of its own over the
+            # same batched launches in a child process (counters need the profiler around the process)
+            out["roofline"]["traffic"] = live[0]
+            out["roofline"]["traffic_measured_in_run"] = True
+            out["roofline"]["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE around a child run of this script's batched launches ({live[1]} launches "
+                                                 "averaged); bytes = FETCH_SIZE (KiB) * 1024 * 2 (gfx950 reports half of wide coalesced reads)")
+            out["roofline"]["achieved_traffic"] = live[0] / kernel_us * 1e-3
+            out["roofline"]["frac_traffic"] = out["roofline"]["achieved_traffic"] / HBM_PEAK_GBS
         try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
             tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))["acx::k_r1cs_sell"]
-            if tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
+            if live is not None and tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
+                out["roofline"]["traffic_committed_pass"] = tr["traffic_bytes_per_launch"]       # the earlier pass, for comparison
+                out["roofline"]["valu_issue"] = _valu_issue("acx::k_r1cs_sell", "valu_wave_insts_per_launch", kernel_us, tr["workload"])
+            elif tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
                 # NOT measured in this run: a constant from the committed rocprofv3 --pmc pass of the same command (PMC
                 # counters need the profiler around the process).  The live quantities of this line are the times.
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
