@@ -728,7 +728,7 @@ def main():
                                 "frac_median": bytes_per_launch / bs[len(bs) // 2] * 1e-3 / HBM_PEAK_GBS,
                                 "note": "kernel times at the sustained clock (0.25 s untimed pre-run before the timed region)"}
         live = None
-        if world == 1 and not a.no_pmc and not a.only_steps:
+        if world == 1 and not use_dist and not a.no_pmc and not a.only_steps:
             live = measure_traffic_live(a)
         if live is not None:
             # HBM bytes of the headline kernel measured in THIS run: a rocprofv3 --pmc FETCH_SIZE pass of its own over the

@@ -974,7 +974,7 @@ def test_bench_force_dist_rccl_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(H.free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "3",
-           "--copies", "4", "--no-cpu", "--no-ntt", "--dist-logn", "18"]
+           "--copies", "4", "--no-cpu", "--no-ntt", "--no-pmc", "--dist-logn", "18"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
