@@ -57,7 +57,7 @@ def effective_cpus():
     return n
 
 
-def measure_traffic_live(a, timeout_s=240):
+def measure_traffic_live(a, timeout_s=120):
     """HBM bytes the headline kernel fetches per launch, measured NOW: this script re-runs its batched launches (only those:
     --only-steps) as a child under `rocprofv3 --pmc FETCH_SIZE` -- a counter pass of its own, no tracing beside it, as
     MI355X_MICROARCH.md prescribes -- and reads the per-dispatch counter values from the profiler's database.  FETCH_SIZE
