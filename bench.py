@@ -57,12 +57,11 @@ def effective_cpus():
     return n
 
 
-def measure_traffic_live(a, timeout_s=120):
-    """HBM bytes the headline kernel fetches per launch, measured NOW: this script re-runs its batched launches (only those:
-    --only-steps) as a child under `rocprofv3 --pmc FETCH_SIZE` -- a counter pass of its own, no tracing beside it, as
-    MI355X_MICROARCH.md prescribes -- and reads the per-dispatch counter values from the profiler's database.  FETCH_SIZE
-    counts KiB and, on gfx950, half of what wide coalesced reads move (calibrated on a copy kernel, tools/prof.py): bytes =
-    value * 1024 * 2.  Returns (bytes per launch, launches averaged) or None when the profiler is missing or fails."""
+def measure_counter_live(a, counter, timeout_s=120):
+    """One hardware counter of the headline kernel, per launch, measured NOW: this script re-runs its batched launches (only
+    those: --only-steps) as a child under `rocprofv3 --pmc <counter>` -- a counter pass of its own, no tracing beside it, as
+    MI355X_MICROARCH.md prescribes -- and reads the per-dispatch values from the profiler's database.  Returns (average value
+    per launch, launches averaged) or None when the profiler is missing or fails."""
     import glob, shutil, sqlite3, subprocess, tempfile
     if shutil.which("rocprofv3") is None:
         return None
@@ -70,20 +69,27 @@ def measure_traffic_live(a, timeout_s=120):
     cmd = [sys.executable, os.path.abspath(__file__), "--only-steps", "--no-cpu", "--no-ntt", "--no-pmc", "--sustain", "0", "--steps", "20",
            "--warmup", "2", "--prewarm", "0.05", "--field", a.field, "--copies", str(a.copies), "--logn", str(a.logn)]
     try:
-        subprocess.call(["rocprofv3", "--pmc", "FETCH_SIZE", "-d", out, "-o", "fetch", "--"] + cmd, stdout=subprocess.DEVNULL,
+        subprocess.call(["rocprofv3", "--pmc", counter, "-d", out, "-o", "pass", "--"] + cmd, stdout=subprocess.DEVNULL,
                         stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=timeout_s)
         best = None
         for db in glob.glob(os.path.join(out, "**", "*.db"), recursive=True):
             cur = sqlite3.connect(db).cursor()
             for name, v, cnt in cur.execute("select kernel_name, avg(value), count(*) from counters_collection "
-                                            "where counter_name = 'FETCH_SIZE' group by kernel_name"):
+                                            "where counter_name = ? group by kernel_name", (counter,)):
                 if "k_r1cs_sell_split" in name and (best is None or cnt > best[1]):
-                    best = (v * 1024.0 * 2.0, cnt)
+                    best = (float(v), cnt)
         return best
     except Exception:                                  # a profiler problem must not cost the line
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def measure_traffic_live(a):
+    """HBM bytes the headline kernel fetches per launch: FETCH_SIZE counts KiB and, on gfx950, half of what wide coalesced
+    reads move (calibrated on a copy kernel, tools/prof.py): bytes = value * 1024 * 2."""
+    r = measure_counter_live(a, "FETCH_SIZE")
+    return None if r is None else (r[0] * 1024.0 * 2.0, r[1])
 
 
 def cpu_baseline(sample, field="bn254", budget_s=12.0):
@@ -739,11 +745,20 @@ def main():
                                                  "averaged); bytes = FETCH_SIZE (KiB) * 1024 * 2 (gfx950 reports half of wide coalesced reads)")
             out["roofline"]["achieved_traffic"] = live[0] / kernel_us * 1e-3
             out["roofline"]["frac_traffic"] = out["roofline"]["achieved_traffic"] / HBM_PEAK_GBS
+        live_valu = measure_counter_live(a, "SQ_INSTS_VALU") if live is not None else None      # second pass, its own run
         try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
             tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))["acx::k_r1cs_sell"]
             if live is not None and tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
                 out["roofline"]["traffic_committed_pass"] = tr["traffic_bytes_per_launch"]       # the earlier pass, for comparison
                 out["roofline"]["valu_issue"] = _valu_issue("acx::k_r1cs_sell", "valu_wave_insts_per_launch", kernel_us, tr["workload"])
+                if live_valu is not None and out["roofline"]["valu_issue"]:
+                    # SQ_INSTS_VALU of this run instead of the committed pass (the issue RATE stays the microbenchmark's)
+                    vi = out["roofline"]["valu_issue"]
+                    vi["issue_bound_us"] *= live_valu[0] / vi["wave_insts"]
+                    vi["wave_insts"] = live_valu[0]
+                    vi["frac"] = vi["issue_bound_us"] / kernel_us
+                    vi["measured_in_run"] = True
+                    vi["source"] = "SQ_INSTS_VALU from a rocprofv3 --pmc pass of this run; issue rate from profiles/r01_valu_rates.txt"
             elif tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
                 # NOT measured in this run: a constant from the committed rocprofv3 --pmc pass of the same command (PMC
                 # counters need the profiler around the process).  The live quantities of this line are the times.
