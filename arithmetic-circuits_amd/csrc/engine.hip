@@ -125,6 +125,11 @@ struct acx_ctx {
         }
     };
     std::map<DistKey, uint4*> tw_dist;
+    // ... a small LRU as well (kDistCap entries; an h(x) pipeline holds three per size): a caller that varies the coset shift
+    // of acx_mgpu_ntt / acx_ntt_dist_step_*_dev must not grow device memory without bound (32 N / world bytes per entry).
+    // The tables are only used by launches issued under ctx->mu on ctx->stream, so eviction needs no pins: synchronise, free.
+    static constexpr size_t kDistCap = 12;
+    std::map<DistKey, uint64_t> tw_dist_stamp;
     std::map<std::pair<uint32_t, std::array<uint64_t, 4>>, uint4*> h_scale;   // (log_n, coset shift) -> {1/z, -1/z} of the h(x) pipeline (get_h_scale)
     NttCfg ntt;
     bool small_coeff = true;                               // use the small-coefficient SELL form where a matrix allows it
@@ -760,7 +765,16 @@ int get_dist_table(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, u
     CtxLock lock(c->mu);
     acx_ctx::DistKey key{log_n, log_r, world, rank, kind, coset ? *coset : H256{{0, 0, 0, 0}}};
     auto it = c->tw_dist.find(key);
-    if (it != c->tw_dist.end()) { *out = it->second; return ACX_OK; }
+    if (it != c->tw_dist.end()) { c->tw_dist_stamp[key] = ++c->coset_clock; *out = it->second; return ACX_OK; }
+    while (c->tw_dist.size() >= acx_ctx::kDistCap) {                 // least recently used entry out
+        auto victim = c->tw_dist_stamp.begin();
+        for (auto s = c->tw_dist_stamp.begin(); s != c->tw_dist_stamp.end(); ++s)
+            if (s->second < victim->second) victim = s;
+        HIP_TRY(hipDeviceSynchronize());                             // launches that still read the table
+        (void)hipFree(c->tw_dist[victim->first]);
+        c->tw_dist.erase(victim->first);
+        c->tw_dist_stamp.erase(victim);
+    }
     const uint64_t L = (1ull << log_n) / world;
     DistTable T{};
     T.log_n = log_n; T.log_r = log_r; T.rank = rank; T.inverse = kind == 1 ? 1u : 0u; T.cols_layout = kind == 2 ? 1u : 0u;
@@ -782,6 +796,7 @@ int get_dist_table(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, u
     const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(cur_stream(c));
     if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(tw); HIP_TRY(e1); HIP_TRY(e2); }
     c->tw_dist[key] = tw;
+    c->tw_dist_stamp[key] = ++c->coset_clock;
     *out = tw;
     return ACX_OK;
 }
@@ -1376,10 +1391,11 @@ int qap_columns_core(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t cnt,
         ColDirect P{};
         P.colptr = T.ptr; P.rowidx = T.idx; P.val = T.val; P.log_n = r->log_n;
         P.steps = (u32)std::max<uint64_t>(1, std::min<uint64_t>(32, N / kBlock));
-        uint4 *lo = nullptr, *hi = nullptr;
+        uint4 *lo = nullptr, *hi = nullptr, *blk = nullptr;
         ACX_TRY(get_low_table(c, r->log_n, 1, &lo));
         if (r->log_n > 10) ACX_TRY(get_pow_table(c, r->log_n - 10, 1, &hi));
-        P.tw_lo = lo; P.tw_hi = hi;
+        ACX_TRY(get_pow_table(c, r->log_n > 8 ? r->log_n - 8 : 0, 1, &blk));     // omega_N^-(256 j): the block / step factors, read by scalar loads
+        P.tw_lo = lo; P.tw_hi = hi; P.tw_blk = blk;
         P.inv_n = dev_arg(c->hf, c->hf.inv(c->hf.from_u64(N)));
         const unsigned gx = (unsigned)std::max<uint64_t>(1, N / ((uint64_t)kBlock * P.steps));
         for (uint64_t b = 0; b < cnt; b += 32768) {
@@ -1497,6 +1513,7 @@ int acx_ctx_set_root(acx_ctx* c, uint32_t two_adicity, const acx_fr* omega) {
     for (auto& kv : c->tw_limbs) (void)hipFree(kv.second);
     for (auto& kv : c->tw_dist) (void)hipFree(kv.second);
     c->tw_dist.clear();
+    c->tw_dist_stamp.clear();
     c->twiddles.clear();
     c->tw_low.clear();
     c->tw_scaled.clear();
@@ -1971,6 +1988,7 @@ int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out) {
 
 // verificationWitnessZk on device-resident data (caller holds ctx->mu): residual dots -> 3 iNTT -> 2 coset NTT (L, R) ->
 // pointwise -> coset iNTT -> minus O0 / z in coefficient form (+ the zero-knowledge terms).  d_h receives N+1 dev elements, not stripped.
+static int get_h_scale(acx_ctx* c, uint32_t log_n, const H256& g, const uint4** out);
 static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4* d_h, unsigned long long* d_result,
                             uint4* d /* 5N elements of scratch */) {
     acx_ctx* c = r->ctx;
@@ -1988,7 +2006,11 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
     // Without the zero-knowledge terms 1/z and -1/z ride on the stored dot products (one product per row in a launch that waits
     // for memory): (L/z) R - O/z is then what the rest of the pipeline forms, with no pass over the product and no scaled
     // subtraction.  The two constants live beside the system (they depend on N alone: r1cs_from_host).
-    ACX_TRY(launch_residual(r, d_w, 0, d_result, nullptr, d, N, 0, 0, zk ? nullptr : (const uint4*)r->d_hscale));
+    // (a system loaded while log_n + 1 exceeded the two-adicity has no pair of its own; acx_ctx_set_root may have raised the
+    // two-adicity since: the context's cache supplies the pair then -- the rest of the pipeline multiplies by one and RELIES on it)
+    const uint4* hscale = r->d_hscale;
+    if (!zk && !hscale) ACX_TRY(get_h_scale(c, r->log_n, g, &hscale));
+    ACX_TRY(launch_residual(r, d_w, 0, d_result, nullptr, d, N, 0, 0, zk ? nullptr : hscale));
     // evaluations on <omega> -> coefficients of L0, R0, O0; L0 and R0 -> evaluations on g<omega>.  O0 stays in coefficient
     // form: h = icoset((L R - O)/z) = icoset(L R / z) - O0 / z by linearity (icoset after coset is the identity), which
     // drops one of the seven transforms.  Without the zero-knowledge terms nobody needs the plain coefficients of L0 and

@@ -164,6 +164,23 @@ __device__ __forceinline__ Fe fe_sub(const Fe& a, const Fe& b) {
     return fe_cond_sub<F::P2>(s);
 }
 
+// P[0] as the multiplier of the quotient digits.  For BLS12-381 Fr the limb is 1 and the compiler turns m * 1 + acc into a
+// 64-bit add of the ZERO-EXTENDED digit -- which pins every digit to an aligned register pair with a zero upper half: nine
+// extra VGPRs in a kernel that lives at the 128-register ceiling (k_ntt_r4).  With ACX_OPAQUE_P0 the limb reaches the
+// product through a scalar register the optimiser cannot see through: the same instruction count (one v_mad_u64_u32 instead
+// of one v_lshl_add_u64), no pairs.
+template <class F>
+__device__ __forceinline__ u32 fe_p0() {
+#if ACX_OPAQUE_P0
+    if (F::P[0] == 1u) {
+        u32 one;
+        asm("s_mov_b32 %0, 1" : "=s"(one));
+        return one;
+    }
+#endif
+    return F::P[0];
+}
+
 // Montgomery product a*b/R mod p, finely integrated product scanning.  a, b: limbs < 2^30,
 // values < 4p.  Result lazy (normalized, < 2p).
 template <class F>
@@ -171,6 +188,7 @@ __device__ __forceinline__ Fe fe_mul(const Fe& a, const Fe& b) {
     u64 acc = 0;
     u32 m[kLimbs];
     Fe r;
+    const u32 p0 = fe_p0<F>();
 #pragma unroll
     for (int k = 0; k < kLimbs; ++k) {
 #pragma unroll
@@ -178,13 +196,50 @@ __device__ __forceinline__ Fe fe_mul(const Fe& a, const Fe& b) {
 #pragma unroll
         for (int i = 0; i < k; ++i) acc += (u64)m[i] * F::P[k - i];
         m[k] = ((u32)acc * F::N0) & kLimbMask;
-        acc += (u64)m[k] * F::P[0];
+        acc += (u64)m[k] * p0;
         acc >>= kLimbBits;
     }
 #pragma unroll
     for (int k = kLimbs; k < 2 * kLimbs - 1; ++k) {
 #pragma unroll
         for (int i = k - kLimbs + 1; i < kLimbs; ++i) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - kLimbs + 1; i < kLimbs; ++i) acc += (u64)m[i] * F::P[k - i];
+        r.l[k - kLimbs] = (u32)acc & kLimbMask;
+        acc >>= kLimbBits;
+    }
+    r.l[kLimbs - 1] = (u32)acc;
+    return r;
+}
+
+// sum_t a[t] * b[t] / R mod p with ONE Montgomery reduction, every limb product of every term chained into the running
+// column accumulator (fe_mul is the case K = 1): 81 K + 90 multiplier instructions and no separate column additions.
+// Operands as fe_mul's; K <= kWideTerms ((9 K + 9) 2^58 < 2^64).  Result lazy (< 2p for operands < 2p: wide_reduce's bound).
+template <class F, int K>
+__device__ __forceinline__ Fe fe_dot(const Fe (&a)[K], const Fe (&b)[K]) {
+    static_assert(K >= 1 && K <= 6, "column accumulators overflow beyond six terms");
+    u64 acc = 0;
+    u32 m[kLimbs];
+    Fe r;
+    const u32 p0 = fe_p0<F>();
+#pragma unroll
+    for (int k = 0; k < kLimbs; ++k) {
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (u64)a[t].l[i] * b[t].l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (u64)m[i] * F::P[k - i];
+        m[k] = ((u32)acc * F::N0) & kLimbMask;
+        acc += (u64)m[k] * p0;
+        acc >>= kLimbBits;
+    }
+#pragma unroll
+    for (int k = kLimbs; k < 2 * kLimbs - 1; ++k) {
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+            for (int i = k - kLimbs + 1; i < kLimbs; ++i) acc += (u64)a[t].l[i] * b[t].l[k - i];
 #pragma unroll
         for (int i = k - kLimbs + 1; i < kLimbs; ++i) acc += (u64)m[i] * F::P[k - i];
         r.l[k - kLimbs] = (u32)acc & kLimbMask;

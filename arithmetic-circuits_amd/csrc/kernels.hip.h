@@ -1,6 +1,7 @@
 // kernels.hip.h -- gfx950 kernels of the R1CS / QAP hot path.  All new code: the reference
 // (pure Haskell) has no kernels; each kernel names the reference computation it performs.
 #pragma once
+#include <utility>
 #include "fr.hip.h"
 #include "mem.hip.h"
 #include "ntt_pass.hip.h"
@@ -1047,11 +1048,17 @@ __global__ __launch_bounds__(kBlock) void k_scatter_columns(const u32* __restric
 
 // `FFT.interpolate` of a SPARSE column without a transform.  A QAP column is the interpolant of a wire's few appearances
 // (an intermediate wire of a Mul-gate circuit has one entry in C and one or two in A / B): with k nonzero values v_t at roots
-// omega^(i_t) the coefficients are c_j = (1/N) sum_t v_t omega^(-i_t j) -- k geometric progressions -- i.e. k Montgomery
-// products per coefficient against the ~10 of the radix-2 transform, no zero fill and no scatter.  Columns with more than
-// kDirectMax entries keep the batched inverse NTT (the host splits a batch into dense runs and the rest).
-// blockIdx.y = column of the batch; a block produces kBlock * L consecutive coefficients, lane l the coefficients
-// base + l + kBlock * s (every store of the block is one contiguous 8 KiB run), stepping each progression by omega^(-256 i_t).
+// omega^(i_t) the coefficients are c_j = (1/N) sum_t v_t omega^(-i_t j) -- k geometric progressions -- against the ~10
+// Montgomery products per coefficient of the radix-2 transform, with no zero fill and no scatter.
+// Coefficient j = 256 (blk + s) + l of lane l at step s factors as
+//     c_j = sum_t  A_t(l) * B_t(blk + s),   A_t(l) = (v_t / N) omega^(-i_t l),   B_t(x) = omega^(-256 i_t x):
+// A_t lives in 9 VGPRs per entry for the whole block, B_t is UNIFORM over the block -- one s_load_dwordx8 per entry and
+// step from the stride-256 power table, unpacked on the scalar unit, and it enters v_mad_u64_u32 as the SGPR operand --
+// and the k products of a coefficient share ONE Montgomery reduction (fe_dot): 81 k + 90 multiplier instructions per
+// coefficient, no running powers, no step factors.
+// Columns with more than kDirectMax entries keep the batched inverse NTT (the host splits a batch into dense runs and the
+// rest).  blockIdx.y = column of the batch; a block produces kBlock * L consecutive coefficients (every store of the block is
+// one contiguous 8 KiB run).
 constexpr u32 kDirectMax = 4;
 struct ColDirect {
     const u32* colptr;
@@ -1062,6 +1069,7 @@ struct ColDirect {
     u32 steps;              // L
     const uint4* tw_lo;     // omega_N^-j, j < min(N, 1024)
     const uint4* tw_hi;     // omega_N^-(1024 j), j < N / 1024 (null for N <= 1024)
+    const uint4* tw_blk;    // omega_N^-(256 j), j < max(1, N / 256)
     FeArg inv_n;            // 1/N (Montgomery)
 };
 
@@ -1071,37 +1079,58 @@ __device__ __forceinline__ Fe omega_inv_pow(const ColDirect& P, u64 e) {     // 
     return fe_mul<F>(fe_gload(P.tw_lo + 2 * (e & 1023u)), fe_gload(P.tw_hi + 2 * (e >> 10)));
 }
 
+// entry t of the column: its row and the lane's factor A_t(l)
+template <class F>
+__device__ __forceinline__ void col_direct_entry(const ColDirect& P, u32 e, u32 l, u64 mask, const Fe& inv_n, Fe& lane, u32& row) {
+    row = sload(P.rowidx + e);
+    const Fe v = fe_mul<F>(fe_sload(P.val + 2 * (u64)e), inv_n);
+    lane = fe_mul<F>(omega_inv_pow<F>(P, ((u64)row * l) & mask), v);
+}
+// (a fold over the entries, not a loop: three products per entry are more than `#pragma unroll` will unroll, and a rolled
+// loop would index lane[] dynamically, i.e. keep it in scratch memory)
+template <class F, int... T>
+__device__ __forceinline__ void col_direct_setup(const ColDirect& P, u32 e0, u32 l, u64 mask, const Fe& inv_n, Fe* lane, u32* row,
+                                                 std::integer_sequence<int, T...>) {
+    (col_direct_entry<F>(P, e0 + T, l, mask, inv_n, lane[T], row[T]), ...);
+}
+
+template <class F, int K>
+__device__ __forceinline__ void col_direct_body(const ColDirect& P, uint4* __restrict__ out, u32 e0) {
+    const u64 N = 1ull << P.log_n, mask = N - 1;
+    const u32 l = threadIdx.x;
+    if (l >= N) return;                                           // N < kBlock
+    const u64 blk = (u64)blockIdx.x * P.steps;                    // in units of kBlock coefficients
+    uint4* dst = out + 2 * (((u64)blockIdx.y << P.log_n) + blk * kBlock + l);
+    const u64 bmask = (N >> 8) ? (N >> 8) - 1 : 0;
+    Fe lane[K];
+    u32 row[K];
+    col_direct_setup<F>(P, e0, l, mask, fe_from_arg(P.inv_n), lane, row, std::make_integer_sequence<int, K>{});
+#pragma unroll 1
+    for (u32 s = 0; s < P.steps; ++s) {
+        Fe b[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) b[t] = fe_sload(P.tw_blk + 2 * (((u64)row[t] * (blk + s)) & bmask));
+        fe_store(dst + 2 * (u64)s * kBlock, fe_dot<F, K>(lane, b));
+    }
+}
+
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_col_direct(ColDirect P, uint4* __restrict__ out) {
     const u64 wire = P.wire_begin + blockIdx.y;
-    const u32 e0 = P.colptr[wire], k = P.colptr[wire + 1] - e0;
-    if (k > kDirectMax) return;                                   // a dense column: the transform's
-    const u64 N = 1ull << P.log_n, mask = N - 1;
-    const u64 j0 = (u64)blockIdx.x * kBlock * P.steps + threadIdx.x;
-    if (j0 >= N) return;                                          // N < kBlock
-    uint4* dst = out + 2 * (((u64)blockIdx.y << P.log_n) + j0);
-    Fe cur[kDirectMax], ratio[kDirectMax];
-    const Fe inv_n = fe_from_arg(P.inv_n);
-#pragma unroll
-    for (u32 t = 0; t < kDirectMax; ++t) {
-        if (t < k) {                                              // k is uniform over the block
-            const u64 i = P.rowidx[e0 + t];
-            const Fe v = fe_mul<F>(fe_gload(P.val + 2 * (u64)(e0 + t)), inv_n);
-            cur[t] = fe_mul<F>(v, omega_inv_pow<F>(P, (i * j0) & mask));
-            ratio[t] = omega_inv_pow<F>(P, (i * kBlock) & mask);
+    const u32 e0 = sload(P.colptr + wire), k = sload(P.colptr + wire + 1) - e0;       // uniform over the block
+    switch (k) {
+        case 0: {                                                 // a wire the matrix never mentions: the zero polynomial
+            const u64 N = 1ull << P.log_n;
+            if (threadIdx.x >= N) break;
+            uint4* dst = out + 2 * (((u64)blockIdx.y << P.log_n) + (u64)blockIdx.x * P.steps * kBlock + threadIdx.x);
+            for (u32 s = 0; s < P.steps; ++s) fe_store(dst + 2 * (u64)s * kBlock, fe_zero());
+            break;
         }
-    }
-#pragma unroll 1
-    for (u32 s = 0; s < P.steps; ++s) {
-        Fe sum = fe_zero();
-#pragma unroll
-        for (u32 t = 0; t < kDirectMax; ++t) {
-            if (t < k) {
-                sum = (t == 0) ? cur[0] : fe_add<F>(sum, cur[t]);
-                if (s + 1 < P.steps) cur[t] = fe_mul<F>(cur[t], ratio[t]);
-            }
-        }
-        fe_store(dst + 2 * (u64)s * kBlock, sum);
+        case 1: col_direct_body<F, 1>(P, out, e0); break;
+        case 2: col_direct_body<F, 2>(P, out, e0); break;
+        case 3: col_direct_body<F, 3>(P, out, e0); break;
+        case 4: col_direct_body<F, 4>(P, out, e0); break;
+        default: break;                                           // a dense column: the transform's
     }
 }
 

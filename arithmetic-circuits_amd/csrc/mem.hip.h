@@ -37,6 +37,14 @@ __device__ __forceinline__ uint2 nt_load(const uint2* p) {
     const v2u32 r = __builtin_nontemporal_load((g_v2u32*)p);
     return make_uint2(r.x, r.y);
 }
+// a wave-uniform element through the scalar cache: one s_load_dwordx8, unpacked on the scalar unit (the limbs stay in SGPRs)
+typedef u32 v8u32 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(4))) const v8u32 c_v8u32;
+__device__ __forceinline__ Fe fe_sload(const uint4* p) {
+    const v8u32 r = *(c_v8u32*)(unsigned long long)p;
+    const u32 w[8] = {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]};
+    return fe_unpack(w);
+}
 __device__ __forceinline__ Fe fe_gload(const uint4* p) {
     const uint4 lo = gload(p), hi = gload(p + 1);
     const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};

@@ -79,7 +79,8 @@ static const RcclApi* rccl_api(std::string& why) {
             if (api.so) break;
         }
         if (!api.so) {
-            err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "");
+            const char* e = dlerror();                                  // ONE call: dlerror() clears the message it returns
+            err = std::string("RCCL not found (dlopen librccl.so.1): ") + (e ? e : "");
         } else {
             auto sym = [&](const char* name) { void* p = dlsym(api.so, name); if (!p && err.empty()) err = std::string("RCCL symbol missing: ") + name; return p; };
             api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
@@ -151,7 +152,8 @@ struct acx_mgpu_r1cs {
         uint4* d_w = nullptr;                       // the replicated witness, m dev elements
         uint4* vec = nullptr;                       // h(x) pipeline: dots 3L | coef 3L | pw L | h L (allocated on first use)
         uint4* hscale = nullptr;                    // {1/z, -1/z} for the GLOBAL N as dev elements: ride on the stored dots of h(x) (qap_h_dev_locked)
-        unsigned long long* ring = nullptr;         // kMgRing result slots {n_bad, first_bad} of the asynchronous form + their reduction
+        unsigned long long* ring = nullptr;         // four sections of kMgRing result slots {n_bad, first_bad}: the asynchronous form's slots,
+                                                    // their reduction, acx_mgpu_r1cs_verify_many's own slots, their reduction
     };
     std::vector<Part> part;
     bool has_cyclic = false;
@@ -660,9 +662,9 @@ int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], 
             HIP_TRY(hipMalloc((void**)&P.hscale, 64));
             HIP_TRY(hipMemcpy(P.hscale, pair, 64, hipMemcpyHostToDevice));
         }
-        HIP_TRY(hipMalloc((void**)&P.ring, 2 * 2 * kMgRing * 8));
-        std::vector<unsigned long long> init(2 * 2 * kMgRing);
-        for (uint32_t i = 0; i < 2 * kMgRing; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
+        HIP_TRY(hipMalloc((void**)&P.ring, 4 * 2 * kMgRing * 8));
+        std::vector<unsigned long long> init(4 * 2 * kMgRing);
+        for (uint32_t i = 0; i < 4 * kMgRing; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
         HIP_TRY(hipMemcpy(P.ring, init.data(), init.size() * 8, hipMemcpyHostToDevice));
         return ACX_OK;
     });
@@ -878,7 +880,12 @@ int acx_mgpu_create(int field, const int* device_ids, uint32_t n_devices, acx_mg
         if (mg->rccl) {
             std::string why;
             mg->api = rccl_api(why);
-            if (!mg->api) return fail(ACX_ERR_UNSUPPORTED, why);
+            // no usable RCCL on this machine: the peer-copy transport carries the same events, buffers and results (an explicit
+            // ACX_MGPU_TRANSPORT=rccl is an error instead: the caller asked for the collectives)
+            if (!mg->api && tr) return fail(ACX_ERR_UNSUPPORTED, why);
+            if (!mg->api) mg->rccl = false;
+        }
+        if (mg->rccl) {
             std::vector<ncclComm_t> comms(n_devices);
             NCCL_TRY(mg, mg->api->CommInitAll(comms.data(), (int)n_devices, device_ids));
             for (uint32_t i = 0; i < n_devices; ++i) mg->sh[i].comm = comms[i];
@@ -1016,8 +1023,9 @@ int acx_mgpu_witness_upload(acx_mgpu_r1cs* mr, const acx_fr* witness) {
 int acx_mgpu_r1cs_verify_resident(acx_mgpu_r1cs* mr, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
     return guarded([&]() -> int {
         if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
-        if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
+        if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
         std::lock_guard<std::mutex> g(mr->mg->mu);
+        if (!mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
         DevGuard dg;
         uint64_t bad = 0, first = ~0ull;
         bool noncanon = false;
@@ -1052,9 +1060,10 @@ int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* mr, const acx_fr* witness, int* ok, uint
 int acx_mgpu_r1cs_verify_enqueue(acx_mgpu_r1cs* mr, uint32_t slot) {
     return guarded([&]() -> int {
         if (!mr || slot >= kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot < 16)");
-        if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
+        if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
         acx_mgpu* mg = mr->mg;
         std::lock_guard<std::mutex> g(mg->mu);
+        if (!mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
         DevGuard dg;
         for (uint32_t s = 0; s < mg->W; ++s) {
             MgShard& S = mg->sh[s];
@@ -1133,22 +1142,40 @@ int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* w
         const uint32_t W = mg->W;
         mr->witness_resident = false;                   // the resident witness is overwritten
         mr->h_valid = false;
-        // second witness buffer per shard, allocated on first use
-        std::vector<uint4*> alt(W, nullptr);
+        // second witness buffer per shard; released on EVERY exit (after the streams have drained)
+        struct AltBuffers {
+            acx_mgpu* mg;
+            std::vector<uint4*> p;
+            ~AltBuffers() {
+                for (uint32_t s = 0; s < p.size(); ++s) {
+                    if (!p[s]) continue;
+                    (void)hipSetDevice(mg->sh[s].device);
+                    (void)hipStreamSynchronize(mg->sh[s].ctx->stream);
+                    (void)hipFree(p[s]);
+                }
+            }
+        } altb{mg, std::vector<uint4*>(W, nullptr)};
+        std::vector<uint4*>& alt = altb.p;
         for (uint32_t s = 0; s < W; ++s) {
             HIP_TRY(hipSetDevice(mg->sh[s].device));
-            if (hipMalloc((void**)&alt[s], mr->m * 32) != hipSuccess) {
-                for (uint32_t t = 0; t < s; ++t) { (void)hipSetDevice(mg->sh[t].device); (void)hipFree(alt[t]); }
-                return fail(ACX_ERR_OOM, "device allocation failed");
-            }
+            if (hipMalloc((void**)&alt[s], mr->m * 32) != hipSuccess) return fail(ACX_ERR_OOM, "device allocation failed");
         }
-        auto cleanup = [&]() {
-            for (uint32_t s = 0; s < W; ++s) { (void)hipSetDevice(mg->sh[s].device); (void)hipStreamSynchronize(mg->sh[s].ctx->stream); (void)hipFree(alt[s]); }
-        };
         for (auto& S : mg->sh) {                        // canonicity flag of the whole call
             HIP_TRY(hipSetDevice(S.device));
             HIP_TRY(hipMemsetAsync(S.d_res + 2, 0, 4, S.ctx->stream));
         }
+        // This call's OWN result slots (section 2 of the ring; their reduction in section 3): slots that
+        // acx_mgpu_r1cs_verify_enqueue has filled and acx_mgpu_r1cs_verdicts has not yet collected are left alone.
+        const uint32_t kMany = 2 * 2 * kMgRing;         // word offset of the section
+        std::vector<unsigned long long> ring_init(2 * kMgRing);
+        for (uint32_t i = 0; i < kMgRing; ++i) { ring_init[2 * i] = 0; ring_init[2 * i + 1] = ~0ull; }
+        auto reset_slots = [&]() {                      // error path: a later call must not see counts of this one
+            for (uint32_t s = 0; s < W; ++s) {
+                (void)hipSetDevice(mg->sh[s].device);
+                (void)hipStreamSynchronize(mg->sh[s].ctx->stream);
+                (void)hipMemcpy(mr->part[s].ring + kMany, ring_init.data(), 16 * kMgRing, hipMemcpyHostToDevice);
+            }
+        };
         int rc = ACX_OK;
         for (uint64_t done = 0; done < count && rc == ACX_OK; done += kMgRing) {
             const uint32_t k = (uint32_t)std::min<uint64_t>(kMgRing, count - done);
@@ -1162,7 +1189,7 @@ int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* w
                     // the stream is in order: the check of witness i-2 (same buffer) precedes this copy
                     HIP_TRY(hipMemcpyAsync(d_w, witnesses + (done + i) * mr->m, mr->m * 32, hipMemcpyHostToDevice, S.ctx->stream));
                     ACX_TRY(launch_convert(S.ctx, true, d_w, d_w, mr->m, (uint32_t*)(S.d_res + 2)));
-                    ACX_TRY(launch_residual(P.slab, d_w, P.row0, P.ring + 2 * i, nullptr, nullptr, 0));
+                    ACX_TRY(launch_residual(P.slab, d_w, P.row0, P.ring + kMany + 2 * i, nullptr, nullptr, 0));
                 }
                 return ACX_OK;
             });
@@ -1174,13 +1201,13 @@ int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* w
             if (mg->rccl) {
                 ncclResult_t r = mg->api->GroupStart();
                 for (uint32_t s = 0; s < W && r == ncclSuccess; ++s)
-                    r = mg->api->AllReduce(mr->part[s].ring, mr->part[s].ring + 2 * kMgRing, 2 * k, ncclUint64, ncclSum, mg->sh[s].comm, mg->sh[s].ctx->stream);
+                    r = mg->api->AllReduce(mr->part[s].ring + kMany, mr->part[s].ring + kMany + 2 * kMgRing, 2 * k, ncclUint64, ncclSum, mg->sh[s].comm, mg->sh[s].ctx->stream);
                 const ncclResult_t r2 = mg->api->GroupEnd();
                 if (r != ncclSuccess || r2 != ncclSuccess) { rc = fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r != ncclSuccess ? r : r2)); break; }
                 for (uint32_t s = 0; s < W; ++s) {
                     (void)hipSetDevice(mg->sh[s].device);
-                    if (s == 0) (void)hipMemcpyAsync(host.data(), mr->part[0].ring + 2 * kMgRing, 16 * k, hipMemcpyDeviceToHost, mg->sh[0].ctx->stream);
-                    (void)hipMemcpyAsync(mr->part[s].ring, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
+                    if (s == 0) (void)hipMemcpyAsync(host.data(), mr->part[0].ring + kMany + 2 * kMgRing, 16 * k, hipMemcpyDeviceToHost, mg->sh[0].ctx->stream);
+                    (void)hipMemcpyAsync(mr->part[s].ring + kMany, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
                 }
                 for (uint32_t s = 0; s < W; ++s) { (void)hipSetDevice(mg->sh[s].device); if (hipStreamSynchronize(mg->sh[s].ctx->stream) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream synchronisation failed"); }
                 for (uint32_t i = 0; i < k; ++i) bad[i] = host[2 * i];
@@ -1188,8 +1215,8 @@ int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* w
                 std::vector<std::vector<unsigned long long>> per(W, std::vector<unsigned long long>(2 * k));
                 for (uint32_t s = 0; s < W; ++s) {
                     (void)hipSetDevice(mg->sh[s].device);
-                    (void)hipMemcpyAsync(per[s].data(), mr->part[s].ring, 16 * k, hipMemcpyDeviceToHost, mg->sh[s].ctx->stream);
-                    (void)hipMemcpyAsync(mr->part[s].ring, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
+                    (void)hipMemcpyAsync(per[s].data(), mr->part[s].ring + kMany, 16 * k, hipMemcpyDeviceToHost, mg->sh[s].ctx->stream);
+                    (void)hipMemcpyAsync(mr->part[s].ring + kMany, init.data(), 16 * k, hipMemcpyHostToDevice, mg->sh[s].ctx->stream);
                 }
                 for (uint32_t s = 0; s < W; ++s) {
                     (void)hipSetDevice(mg->sh[s].device);
@@ -1208,7 +1235,7 @@ int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* w
             if (hipMemcpy(&flag, mg->sh[0].d_res + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ACX_ERR_HIP, "flag fetch failed");
             else if (flag) rc = fail(ACX_ERR_NONCANONICAL, "element >= p");
         }
-        cleanup();
+        if (rc != ACX_OK) reset_slots();
         return rc;
     });
 }
@@ -1216,10 +1243,11 @@ int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* w
 int acx_mgpu_qap_h_resident(acx_mgpu_r1cs* mr, const acx_fr* delta, int* ok) {
     return guarded([&]() -> int {
         if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
-        if (!mr->sharded || !mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
+        if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
         H256 dl[3];
         if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], mr->mg->sh[0].ctx->hf, dl[k]));
         std::lock_guard<std::mutex> g(mr->mg->mu);
+        if (!mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
         DevGuard dg;
         bool good = false;
         ACX_TRY(mg_qap_h_resident(mr, delta ? dl : nullptr, &good));
@@ -1228,24 +1256,30 @@ int acx_mgpu_qap_h_resident(acx_mgpu_r1cs* mr, const acx_fr* delta, int* ok) {
     });
 }
 
+// h of the resident witness from the devices' COLS blocks into natural order (caller holds mg->mu)
+static int mg_qap_h_fetch_locked(acx_mgpu_r1cs* mr, acx_fr* out_h, uint64_t* h_len) {
+    if (!mr->h_valid) return fail(ACX_ERR_UNSUPPORTED, "no h(x) on the devices (acx_mgpu_qap_h_resident)");
+    acx_mgpu* mg = mr->mg;
+    const uint64_t N = 1ull << mr->log_n, L = N / mg->W, R = 1ull << mr->log_r, C = N / R;
+    ACX_TRY(mg_ensure_io(mg, L));
+    std::vector<uint4*> hp(mg->W);
+    for (uint32_t s = 0; s < mg->W; ++s) hp[s] = mr->part[s].vec + 2 * 7 * L;
+    ACX_TRY(mg_fetch_natural(mg, hp.data(), R, C / mg->W, C, out_h));                         // COLS ownership
+    write_h256(&out_h[N], mg->sh[0].ctx->hf, mr->h_top);
+    uint64_t len = N + 1;
+    static const uint8_t zero32[32] = {0};
+    while (len > 0 && std::memcmp(out_h[len - 1].b, zero32, 32) == 0) --len;
+    *h_len = len;
+    return ACX_OK;
+}
+
 int acx_mgpu_qap_h_fetch(acx_mgpu_r1cs* mr, acx_fr* out_h, uint64_t* h_len) {
     return guarded([&]() -> int {
         if (!mr || !out_h || !h_len) return fail(ACX_ERR_INVALID_ARG, "null argument");
-        if (!mr->sharded || !mr->h_valid) return fail(ACX_ERR_UNSUPPORTED, "no h(x) on the devices (acx_mgpu_qap_h_resident)");
-        acx_mgpu* mg = mr->mg;
-        std::lock_guard<std::mutex> g(mg->mu);
+        if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "no h(x) on the devices (acx_mgpu_qap_h_resident)");
+        std::lock_guard<std::mutex> g(mr->mg->mu);
         DevGuard dg;
-        const uint64_t N = 1ull << mr->log_n, L = N / mg->W, R = 1ull << mr->log_r, C = N / R;
-        ACX_TRY(mg_ensure_io(mg, L));
-        std::vector<uint4*> hp(mg->W);
-        for (uint32_t s = 0; s < mg->W; ++s) hp[s] = mr->part[s].vec + 2 * 7 * L;
-        ACX_TRY(mg_fetch_natural(mg, hp.data(), R, C / mg->W, C, out_h));                         // COLS ownership
-        write_h256(&out_h[N], mg->sh[0].ctx->hf, mr->h_top);
-        uint64_t len = N + 1;
-        static const uint8_t zero32[32] = {0};
-        while (len > 0 && std::memcmp(out_h[len - 1].b, zero32, 32) == 0) --len;
-        *h_len = len;
-        return ACX_OK;
+        return mg_qap_h_fetch_locked(mr, out_h, h_len);
     });
 }
 
@@ -1268,16 +1302,16 @@ int acx_mgpu_qap_h(acx_mgpu_r1cs* mr, const acx_fr* witness, const acx_fr* delta
         }
         H256 dl[3];
         if (delta) for (int k = 0; k < 3; ++k) ACX_TRY(read_h256(&delta[k], mr->mg->sh[0].ctx->hf, dl[k]));
-        {
-            std::lock_guard<std::mutex> g(mr->mg->mu);
-            DevGuard dg;
-            ACX_TRY(mg_upload_witness(mr, witness));
-            bool good = false;
-            const int rc = mg_qap_h_resident(mr, delta ? dl : nullptr, &good);
-            if (rc != ACX_OK) { if (rc == ACX_ERR_NONCANONICAL) mr->witness_resident = false; return rc; }
-            *ok = good;
-        }
-        return acx_mgpu_qap_h_fetch(mr, out_h, h_len);
+        // ONE critical section from the upload to the fetch: another thread's call on this handle cannot overwrite the
+        // devices' vectors between the pipeline and the read-back
+        std::lock_guard<std::mutex> g(mr->mg->mu);
+        DevGuard dg;
+        ACX_TRY(mg_upload_witness(mr, witness));
+        bool good = false;
+        const int rc = mg_qap_h_resident(mr, delta ? dl : nullptr, &good);
+        if (rc != ACX_OK) { if (rc == ACX_ERR_NONCANONICAL) mr->witness_resident = false; return rc; }
+        *ok = good;
+        return mg_qap_h_fetch_locked(mr, out_h, h_len);
     });
 }
 

@@ -80,6 +80,9 @@ __device__ __forceinline__ void r4_round(Fe (&x)[4], const uint4* __restrict__ t
         const Fe a1 = fe_add_lazy<false>(x[2], t3), s1 = fe_sub_lazy<F, false>(x[2], t3);
         x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
     }
+#if ACX_R4_SB
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (stage_b) {
         const Fe w1 = fe_load_limbs(tw, iB1);
         Fe t2;
@@ -110,7 +113,10 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
     const u32 odd = (u32)LP - ls;
     const u32 S = 1u << ls;
     const u32 t = threadIdx.x, g = t >> LU, u = t & (U - 1);
-    const u32 v = __brev(u) >> (32 - LU);    // logical lane index: holds the already-processed position bits
+    // logical lane index v = bitrev(u): holds the already-processed position bits.  Two instructions from u, and recomputed where
+    // it is used (behind an optimisation barrier) instead of being held across the rounds: the instances of 1024 threads sit
+    // at the 128-register ceiling, and this was the register that went to scratch memory.
+    auto lane_v = [&]() { u32 uu = u; asm("" : "+v"(uu)); return __brev(uu) >> (32 - LU); };
     const u32 gbase = g * (4u * U);
 
     u64 base_in = 0, base_out = 0, K0 = 0, I0 = 0;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
             if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         }
         // round r: twiddle exponents from the processed position bits jlow = v mod 4^r
-        const u32 jlow = v & ((1u << (2 * r)) - 1u);
+        const u32 jlow = lane_v() & ((1u << (2 * r)) - 1u);
         const bool stage_b = !(r == R - 1 && odd);
         const u64 iA = (u64)jlow << (ls - 1 - 2 * r);
         const u64 iB0 = stage_b ? ((u64)jlow << (ls - 2 - 2 * r)) : 0;
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(1 << (LP - 2 + LG)) void k_ntt_r4(NttPass P) {
     // ---- closing: inter-pass twiddle / scale / coset factor (one multiplication) or plain reduction; store.
     // Slot e = output digit (e << LU) | v; the slots rotate through x[0] so that the loop body exists once.
     const Fe scale = fe_from_arg(P.scale);
+    const u32 v = lane_v();
 #pragma unroll 1
     for (u32 e = 0; e < 4; ++e) {
         const Fe cur = x[0];
