@@ -166,18 +166,16 @@ __device__ __forceinline__ Fe fe_sub(const Fe& a, const Fe& b) {
 
 // P[0] as the multiplier of the quotient digits.  For BLS12-381 Fr the limb is 1 and the compiler turns m * 1 + acc into a
 // 64-bit add of the ZERO-EXTENDED digit -- which pins every digit to an aligned register pair with a zero upper half: nine
-// extra VGPRs in a kernel that lives at the 128-register ceiling (k_ntt_r4).  With ACX_OPAQUE_P0 the limb reaches the
-// product through a scalar register the optimiser cannot see through: the same instruction count (one v_mad_u64_u32 instead
-// of one v_lshl_add_u64), no pairs.
+// extra VGPRs in kernels that live at the 128-register ceiling (k_ntt_r4: four BLS12-381 instances at 129-133 registers =
+// 3 waves per SIMD, two spilling; profiles/r04_ntt.txt).  The limb therefore reaches the product through a scalar register
+// the optimiser cannot see through: the same instruction count (one v_mad_u64_u32 instead of one v_lshl_add_u64), no pairs.
 template <class F>
 __device__ __forceinline__ u32 fe_p0() {
-#if ACX_OPAQUE_P0
     if (F::P[0] == 1u) {
         u32 one;
         asm("s_mov_b32 %0, 1" : "=s"(one));
         return one;
     }
-#endif
     return F::P[0];
 }
 

@@ -80,9 +80,9 @@ __device__ __forceinline__ void r4_round(Fe (&x)[4], const uint4* __restrict__ t
         const Fe a1 = fe_add_lazy<false>(x[2], t3), s1 = fe_sub_lazy<F, false>(x[2], t3);
         x[0] = a0; x[1] = s0; x[2] = a1; x[3] = s1;
     }
-#if ACX_R4_SB
+    // stage B's twiddle loads and products stay behind stage A: hoisted above it they cost the registers that sent
+    // k_ntt_r4<*,10,2> to scratch memory (profiles/r04_ntt.txt: same speed, no spill)
     __builtin_amdgcn_sched_barrier(0);
-#endif
     if (stage_b) {
         const Fe w1 = fe_load_limbs(tw, iB1);
         Fe t2;

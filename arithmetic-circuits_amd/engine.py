@@ -328,6 +328,7 @@ class Circuit:
         self.lib = _lib.load()
         self.field = field
         self._keep = keep
+        self._gate_list = gate_list            # the marshalled form itself (its arrays are in _keep): re-creatable, e.g. to time acx_circuit_create
         h = C.c_void_p()
         check(self.lib.acx_circuit_create(FIELDS[field][0], C.byref(gate_list), C.byref(h)))
         self._h = h

@@ -27,6 +27,25 @@ acx = importlib.import_module("arithmetic-circuits_amd")
 synth = importlib.import_module("arithmetic-circuits_amd.synth")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+T_START = time.perf_counter()
+
+# Every secondary measurement runs under guard(): a failure becomes an entry of the line's "errors" list instead of costing
+# the line (the headline `value` is measured before any of them).
+ERRORS = []
+PHASES = {}
+
+
+def guard(where, fn, *args, **kw):
+    t0 = time.perf_counter()
+    try:
+        return fn(*args, **kw)
+    except BaseException as e:                      # AssertionError of a parity gate included
+        if isinstance(e, (KeyboardInterrupt, SystemExit)):
+            raise
+        ERRORS.append({"where": where, "error": (type(e).__name__ + ": " + str(e))[:400]})
+        return None
+    finally:
+        PHASES[where] = round(PHASES.get(where, 0.0) + time.perf_counter() - t0, 3)
 
 
 def algorithmic_bytes(mats, n):
@@ -57,16 +76,16 @@ def effective_cpus():
     return n
 
 
-def measure_counter_live(a, counter, timeout_s=120):
-    """One hardware counter of the headline kernel, per launch, measured NOW: this script re-runs its batched launches (only
-    those: --only-steps) as a child under `rocprofv3 --pmc <counter>` -- a counter pass of its own, no tracing beside it, as
-    MI355X_MICROARCH.md prescribes -- and reads the per-dispatch values from the profiler's database.  Returns (average value
-    per launch, launches averaged) or None when the profiler is missing or fails."""
+def measure_counter_live(a, counter, kernel="k_r1cs_sell_split", child=("--only-steps",), timeout_s=120):
+    """One hardware counter of one kernel, per launch, measured NOW: this script re-runs its launches of that kernel (only
+    those: --only-steps / --only-ntt) as a child under `rocprofv3 --pmc <counter>` -- a counter pass of its own, no tracing
+    beside it, as MI355X_MICROARCH.md prescribes -- and reads the per-dispatch values from the profiler's database.  Returns
+    (average value per launch, launches averaged) or None when the profiler is missing or fails."""
     import glob, shutil, sqlite3, subprocess, tempfile
     if shutil.which("rocprofv3") is None:
         return None
     out = tempfile.mkdtemp(prefix="acx_pmc_", dir="/tmp")
-    cmd = [sys.executable, os.path.abspath(__file__), "--only-steps", "--no-cpu", "--no-ntt", "--no-pmc", "--sustain", "0", "--steps", "20",
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(child) + ["--skip", "all", "--sustain", "0", "--steps", "20",
            "--warmup", "2", "--prewarm", "0.05", "--field", a.field, "--copies", str(a.copies), "--logn", str(a.logn)]
     try:
         subprocess.call(["rocprofv3", "--pmc", counter, "-d", out, "-o", "pass", "--"] + cmd, stdout=subprocess.DEVNULL,
@@ -74,10 +93,10 @@ def measure_counter_live(a, counter, timeout_s=120):
         best = None
         for db in glob.glob(os.path.join(out, "**", "*.db"), recursive=True):
             cur = sqlite3.connect(db).cursor()
-            for name, v, cnt in cur.execute("select kernel_name, avg(value), count(*) from counters_collection "
+            for name, v, cnt in cur.execute("select kernel_name, sum(value), count(*) from counters_collection "
                                             "where counter_name = ? group by kernel_name", (counter,)):
-                if "k_r1cs_sell_split" in name and (best is None or cnt > best[1]):
-                    best = (float(v), cnt)
+                if kernel in name:
+                    best = (float(v) + (best[0] if best else 0.0), cnt + (best[1] if best else 0))     # every instance of the kernel
         return best
     except Exception:                                  # a profiler problem must not cost the line
         return None
@@ -89,7 +108,7 @@ def measure_traffic_live(a):
     """HBM bytes the headline kernel fetches per launch: FETCH_SIZE counts KiB and, on gfx950, half of what wide coalesced
     reads move (calibrated on a copy kernel, tools/prof.py): bytes = value * 1024 * 2."""
     r = measure_counter_live(a, "FETCH_SIZE")
-    return None if r is None else (r[0] * 1024.0 * 2.0, r[1])
+    return None if r is None else (r[0] / r[1] * 1024.0 * 2.0, r[1])
 
 
 def cpu_baseline(sample, field="bn254", budget_s=12.0):
@@ -118,19 +137,34 @@ def cpu_baseline(sample, field="bn254", budget_s=12.0):
     return out
 
 
+_REF_CASE = {}
+
+
+def ref_case(field="bn254", log_n=10):
+    """configs[0] (the reference's CPU-runnable case scaled to 2^10 gates): the circuit, its rows and witness,
+    and the ORACLE's createPolynomialsFFT of it (3 m dense interpolations, single threaded like the reference; timed).  Built
+    once per run: the CPU baseline's reference-algorithm leg and the GPU-side `reference_bench` parity gate share it."""
+    if field not in _REF_CASE:
+        from oracle.c_oracle import COracle
+        orc = COracle(field)
+        n = 1 << log_n
+        s = synth.mulgraph(n, n_in=64, seed=0xAC1, field=field)
+        mats, w = s.rows(), s.witness()
+        m = w.shape[0]
+        t0 = time.perf_counter()
+        cols = np.stack([orc.qap_columns(n, log_n, mats[k], 0, m, nthreads=1) for k in range(3)])
+        _REF_CASE[field] = {"s": s, "mats": mats, "w": w, "m": m, "n": n, "log_n": log_n, "cols": cols, "t_create": time.perf_counter() - t0, "orc": orc}
+    return _REF_CASE[field]
+
+
 def cpu_reference_algorithm(orc, field="bn254", log_n=10):
     """BASELINE.md section 2 / SURVEY.md 8(d), configs[0] (the reference's CPU-runnable case, 2^10 gates): what the Haskell
     ALGORITHM costs -- createPolynomialsFFT into dense per-wire polynomials (src/QAP.hs:512-525: 3 m interpolations) and
     verifyAssignment in the polynomial domain (src/QAP.hs:276-327: m scalar x polynomial sums per matrix, dense product,
     long division by x^N - 1), single threaded like the reference.  A C restatement (oracle/acx_oracle.c orc_qap_columns,
     orc_ref_verify), NOT GHC: boxed Naturals and lazy lists cost more than this."""
-    n = 1 << log_n
-    s = synth.mulgraph(n, n_in=64, seed=0xAC1, field=field)
-    mats, w = s.rows(), s.witness()
-    m = w.shape[0]
-    t0 = time.perf_counter()
-    cols = np.stack([orc.qap_columns(n, log_n, mats[k], 0, m, nthreads=1) for k in range(3)])
-    t_create = time.perf_counter() - t0
+    rc = ref_case(field, log_n)
+    n, m, mats, w, cols = rc["n"], rc["m"], rc["mats"], rc["w"], rc["cols"]
     reps, t0 = 0, time.perf_counter()
     while reps < 3 or time.perf_counter() - t0 < 1.0:
         q, ok = orc.ref_verify(m, log_n, cols, w)
@@ -140,9 +174,115 @@ def cpu_reference_algorithm(orc, field="bn254", log_n=10):
     h, ok2 = orc.qap_h(n, m, log_n, *mats, w)
     assert ok2 and np.array_equal(h[:n], q) and not h[n:].any(), "polynomial-domain quotient differs from the evaluation-domain h(x)"
     return {"config": f"configs[0]: 2^{log_n}-gate mulgraph circuit, m = {m} wires ({field} Fr)", "cores": 1,
-            "create_qap_s": t_create, "verify_s": t_verify, "constraints_per_s": n / t_verify,
+            "create_qap_s": rc["t_create"], "verify_s": t_verify, "constraints_per_s": n / t_verify,
             "note": "C restatement of the reference's polynomial-domain algorithm (3 m dense interpolations; m scalar x polynomial "
                     "sums per matrix, dense product, long division), not GHC; quotient checked against the evaluation-domain h(x)"}
+
+
+def reference_bench(ctx, field="bn254"):
+    """The reference's OWN benchmarked operations (bench/Circuit.hs:26-36: criterion on `evalArithCircuit`,
+    `arithCircuitToGenQAP` "no interpolation", `arithCircuitToQAPFFT` "fast interpolation", `arithCircuitToQAP` "slow") through
+    the C ABI on configs[0]'s 2^10-gate circuit -- wall clock per operation as a host would see it, blocking calls, host
+    buffers in and (where the reference returns a value the host reads) out.  Every result is parity-gated: the evaluated
+    witness equals the host fold's and satisfies the ORACLE's check; all 3 m FFT-path polynomials equal the oracle's
+    coefficient for coefficient; the naive-path target vanishes on every root and a naive column takes its matrix's
+    values on every root (degree < n: that determines it)."""
+    rc = ref_case(field)
+    s, mats, w, m, n, log_n, orc = rc["s"], rc["mats"], rc["w"], rc["m"], rc["n"], rc["log_n"], rc["orc"]
+    p = acx.engine.FIELDS[field][1]
+    c = s.circuit
+
+    def wall(fn, reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    out = {"config": f"configs[0]: 2^{log_n}-gate mulgraph circuit, m = {m} wires, N = {n} ({field} Fr); the four criterion benchmarks of bench/Circuit.hs:28-35"}
+    # 1. evalArithCircuit / generateAssignment: acx_r1cs_eval (level-parallel on the GPU), acx_circuit_eval (host fold) beside it
+    r = c.to_r1cs(ctx)
+    gw, _ = r.eval_witness(s.inputs)
+    _, nbad, _ = orc.r1cs_residuals(n, m, *mats, gw, want_residuals=False)
+    ok_eval = bool(np.array_equal(gw, w) and nbad == 0)
+    out["evalArithCircuit"] = {"gpu_acx_r1cs_eval_s": wall(lambda: r.eval_witness(s.inputs), 20),
+                               "gpu_resident_no_download_s": wall(lambda: r.eval_witness(s.inputs, download=False), 20),
+                               "host_acx_circuit_eval_s": wall(lambda: c.eval(s.inputs), 20), "parity_vs_oracle": ok_eval,
+                               "note": "a 2^10-gate chain has ~10^3 levels of one gate or a few: launch-latency bound on a GPU; the host fold is the fast path at this size"}
+
+    # 2. arithCircuitToGenQAP: acx_circuit_create + acx_circuit_to_r1cs
+    def gen_qap():
+        c2 = acx.Circuit(field, c._gate_list, c._keep)
+        r2 = c2.to_r1cs(ctx)
+        ctx.sync()
+        return c2, r2
+
+    def gen_qap_drop():
+        c2, r2 = gen_qap()
+        r2.close(); c2.close()
+
+    rp, col, val = r.export(0)
+    out["arithCircuitToGenQAP"] = {"s": wall(gen_qap_drop, 10), "calls": "acx_circuit_create + acx_circuit_to_r1cs",
+                                   "parity_vs_oracle": bool(np.array_equal(rp, mats[0][0]) and np.array_equal(col, mats[0][1]) and np.array_equal(val, mats[0][2]))}
+    # 3. arithCircuitToQAPFFT: the same + all 3 m per-wire polynomials (createPolynomialsFFT), device resident and to the host
+    bufs = [torch.empty((m * n, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+    lens = torch.zeros((3, m), dtype=torch.int64, device="cuda")
+
+    def qap_fft():
+        c2, r2 = gen_qap()
+        for k in range(3):
+            r2.qap_columns_dev(k, 0, m, bufs[k].data_ptr(), lens[k].data_ptr())
+        ctx.sync()
+        r2.close(); c2.close()
+
+    t_fft = wall(qap_fft, 5)
+    ok_cols = True
+    for k in range(3):
+        got = _from_dev(ctx, bufs[k], m * n).reshape(m, n, 4)
+        ok_cols = ok_cols and bool(np.array_equal(got, rc["cols"][k]))
+
+    def qap_fft_host():
+        c2, r2 = gen_qap()
+        for k in range(3):
+            r2.qap_columns(k, 0, m)
+        r2.close(); c2.close()
+
+    out["arithCircuitToQAPFFT"] = {"s": t_fft, "to_host_buffers_s": wall(qap_fft_host, 2), "polynomials": 3 * m, "coefficients": 3 * m * n,
+                                   "calls": "acx_circuit_create + acx_circuit_to_r1cs + 3 x acx_qap_columns_dev (all m wires); to_host_buffers: acx_qap_columns (D2H of every coefficient)",
+                                   "parity_vs_oracle": ok_cols, "cpu_restatement_s": rc["t_create"]}
+    # 4. arithCircuitToQAP ("slow": Lagrange on the roots 0 .. n-1, target prod (x - r)): acx_naive_create + target + 3 x columns
+    roots = list(range(n))
+    keep = {}
+
+    def qap_naive():
+        c2, r2 = gen_qap()
+        nv = acx.Naive(r2, roots)
+        keep["target"] = nv.target()
+        keep["cols"] = [nv.columns(k, 0, m) for k in range(3)]
+        nv.close(); r2.close(); c2.close()
+
+    t_naive = wall(qap_naive, 2)
+
+    def horner(coeffs, x):
+        acc = 0
+        for cf in reversed(coeffs):
+            acc = (acc * x + cf) % p
+        return acc
+    tgt = acx.fr_to_ints(keep["target"])
+    ok_naive = tgt[-1] == 1 and len(tgt) == n + 1 and all(horner(tgt, x) == 0 for x in roots)
+    wire = int(mats[0][1][mats[0][0][n // 2]])                       # a wire row n/2 of A mentions
+    poly = acx.fr_to_ints(keep["cols"][0][0][wire])
+    dense = [0] * n
+    rp, col, val = mats[0]
+    for i in range(n):
+        for e in range(int(rp[i]), int(rp[i + 1])):
+            if int(col[e]) == wire:
+                dense[i] = (dense[i] + acx.fr_to_ints(val[e:e + 1])[0]) % p
+    ok_naive = bool(ok_naive and all(horner(poly, x) == dense[x] for x in roots))
+    out["arithCircuitToQAP"] = {"s": t_naive, "calls": "acx_circuit_create + acx_circuit_to_r1cs + acx_naive_create + acx_naive_target + 3 x acx_naive_columns (all m wires, host buffers)",
+                                "polynomials": 3 * m, "parity_vs_interpolation_conditions": ok_naive}
+    r.close()
+    return out
 
 
 def _timed(stream, fn, reps, prewarm):
@@ -170,17 +310,26 @@ def _from_dev(ctx, t, count):
     return out.cpu().numpy().view(np.uint64).reshape(-1, 4)[:count]
 
 
-def _valu_issue(key, count_field, us, workload):
-    """VALU-issue fraction of a kernel: SQ_INSTS_VALU (wave instructions per launch, from the committed rocprofv3 --pmc
-    pass of the same workload) / 1024 SIMDs / the measured multiplier issue rate, over the live launch time."""
+def _valu_rate():
+    """measured integer-multiplier issue rate (tools/microbench/valu_rates.hip -> profiles/r01_valu_rates.txt), via the committed table"""
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+    return tr["valu_rate"]["simds"], tr["valu_rate"]["wave_insts_per_s_per_simd"], tr
+
+
+def _valu_issue(key, count_field, us, workload, live_count=None):
+    """VALU-issue fraction of a kernel: SQ_INSTS_VALU (wave instructions per launch: `live_count` from a rocprofv3 --pmc pass of
+    THIS run, else the committed pass of the same workload) / 1024 SIMDs / the measured multiplier issue rate, over the live
+    launch time."""
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
-        if tr[key]["workload"] != workload:
-            return None
-        rate = tr["valu_rate"]
-        bound_us = tr[key][count_field] / rate["simds"] / rate["wave_insts_per_s_per_simd"] * 1e6
-        return {"wave_insts": tr[key][count_field], "issue_bound_us": bound_us, "frac": bound_us / us,
-                "source": "profiles/r03_traffic.json, profiles/r01_valu_rates.txt", "measured_in_run": False}
+        simds, rate, tr = _valu_rate()
+        if live_count is None:
+            if tr[key]["workload"] != workload:
+                return None
+            count, measured, src = tr[key][count_field], False, "profiles/r03_traffic.json, profiles/r01_valu_rates.txt"
+        else:
+            count, measured, src = live_count, True, "SQ_INSTS_VALU from a rocprofv3 --pmc pass of this run; issue rate from profiles/r01_valu_rates.txt"
+        bound_us = count / simds / rate * 1e6
+        return {"wave_insts": count, "issue_bound_us": bound_us, "frac": bound_us / us, "source": src, "measured_in_run": measured}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -192,11 +341,12 @@ def _hbm(alg_bytes, us, **extra):
     return d
 
 
-def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=40, prewarm=0.25, batch=64):
+def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=40, prewarm=0.25, batch=64, live_valu=None):
     """Secondary metrics of configs[2]: one 2^20-point transform (= FFT.interpolate of one QAP
     column) and a batch of 64 of them.  Parity gate first: the inverse transform of a fixed random vector is
     compared with the C oracle's, element by element.  The timed loop alternates inverse and forward on that
-    vector, so every launch works on the same data (inverse then forward is the identity)."""
+    vector, so every launch works on the same data (inverse then forward is the identity).  live_valu: SQ_INSTS_VALU per
+    transform from this run's own counter pass (measure_ntt_valu_live)."""
     from oracle.c_oracle import COracle
     orc = COracle(field)
     n = 1 << log_n
@@ -214,37 +364,100 @@ def bench_ntt(ctx, stream, field="bn254", log_n=20, reps=40, prewarm=0.25, batch
 
     us = _timed(stream, one, reps, prewarm)
     ops = 1.5 * n * log_n + n / 2          # butterflies * 3, + the 1/N scaling of the inverse half of the launches
-    xb = to_dev(ctx, synth.random_fr(n * batch, 6, 1, field))
-    flipb = [False]
-
-    def many():
-        flipb[0] = not flipb[0]
-        ctx.ntt_dev(xb.data_ptr(), log_n, batch, inverse=flipb[0])
-
-    us_b = _timed(stream, many, 6, prewarm) / batch
     alg = 128 * n      # two reads + two writes of every 32-byte element (two-pass four-step)
     note = ("VALU-bound: ~10 Montgomery products (171 v_mad_u64_u32 each) per element; the HBM fraction is what "
             "SURVEY.md 8(d) asks to be quoted, valu_issue is the fraction of the integer-issue bound (profiles/r02_ntt.txt)")
-    return {"workload": f"NTT N=2^{log_n} ({field} Fr), alternating inverse/forward on a fixed vector, acx::k_ntt_r4",
-            "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6,
-            "roofline": _hbm(alg, us, note=note, valu_issue=_valu_issue("acx::k_ntt_r4", "valu_wave_insts_per_transform", us,
-                                                                        {"field": field, "logn": log_n})),
-            "batch": {"transforms": batch, "us_per_transform": us_b, "field_ops_per_s": ops / us_b * 1e6,
-                      "roofline": _hbm(alg, us_b)}}
+    out = {"workload": f"NTT N=2^{log_n} ({field} Fr), alternating inverse/forward on a fixed vector, acx::k_ntt_r4",
+           "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6,
+           "roofline": _hbm(alg, us, note=note, valu_issue=_valu_issue("acx::k_ntt_r4", "valu_wave_insts_per_transform", us,
+                                                                       {"field": field, "logn": log_n}, live_valu))}
+    if batch:
+        xb = to_dev(ctx, synth.random_fr(n * batch, 6, 1, field))
+        flipb = [False]
+
+        def many():
+            flipb[0] = not flipb[0]
+            ctx.ntt_dev(xb.data_ptr(), log_n, batch, inverse=flipb[0])
+
+        us_b = _timed(stream, many, 6, prewarm) / batch
+        out["batch"] = {"transforms": batch, "us_per_transform": us_b, "field_ops_per_s": ops / us_b * 1e6, "roofline": _hbm(alg, us_b)}
+    return out
 
 
-def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
+def only_ntt(a):
+    """child of the NTT counter pass (--only-ntt): nothing but `reps` single 2^20-point transforms on a resident vector"""
+    ctx = acx.Context(a.field, 0)
+    x = to_dev(ctx, synth.random_fr(1 << 20, 5, 1, a.field))
+    for i in range(2 * 20):
+        ctx.ntt_dev(x.data_ptr(), 20, 1, inverse=bool(i & 1))
+    ctx.sync()
+    print(json.dumps({"transforms": 40}))
+
+
+def measure_ntt_valu_live(a):
+    """SQ_INSTS_VALU of one 2^20-point transform measured in THIS run: the pass kernels' counts of a child that runs 40
+    transforms and nothing else (its conversion kernel is not a k_ntt_r4), summed over the launches, / 40."""
+    r = measure_counter_live(a, "SQ_INSTS_VALU", kernel="k_ntt_r4", child=("--only-ntt",))
+    return None if r is None or r[1] == 0 else r[0] / 40.0
+
+
+class C3System:
+    """BASELINE.json configs[2] / configs[4]: ONE 2^20-gate mulgraph circuit (2^20 constraints), built once and shared by the
+    `load`, `qap_h`, `qap_columns` and `e2e` objects.  prepare() is pure host work (numpy + acx_circuit_create: no device) and
+    may run on a helper thread while the counter passes keep the GPU busy; load() puts it on the device and times that."""
+
+    def __init__(self, field, log_n=20, seed=0xAC3):
+        self.field, self.log_n, self.seed = field, log_n, seed
+        self.s = self.mats = self.w = self.r = self.dw = None
+        self.t = {}
+
+    def prepare(self):
+        t0 = time.perf_counter()
+        self.s = synth.mulgraph(1 << self.log_n, seed=self.seed, field=self.field)
+        self.t["synth_and_create_s"] = time.perf_counter() - t0
+        self.mats, self.w = self.s.rows(), self.s.witness()
+        return self
+
+    def load(self, ctx):
+        c = self.s.circuit
+        t0 = time.perf_counter()
+        again = acx.Circuit(self.field, c._gate_list, c._keep)      # acx_circuit_create alone, on the marshalled gate list
+        self.t["circuit_create_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        self.r = again.to_r1cs(ctx)                                  # acx_circuit_to_r1cs: rows -> CSR + SELL-64 on the device
+        ctx.sync()
+        self.t["to_r1cs_s"] = time.perf_counter() - t0
+        again.close()
+        self.dw = to_dev(ctx, self.w)
+        return self
+
+
+def bench_load(c3):
+    """configs[2]'s load path (`arithCircuitToGenQAP`, src/QAP.hs:530-539, at 2^20 gates): marshalled gate list ->
+    acx_circuit_create (validation, Montgomery conversion, gateToGenQAP rows on the host's cores) -> acx_circuit_to_r1cs
+    (device CSR + SELL-64).  Parity: the device system's rows exported again equal the host rows the oracle checks
+    (first matrix, sampled rows) and the satisfying witness is accepted (bench_qap_h's gate covers every row through h)."""
+    n = 1 << c3.log_n
+    rp, col, val = c3.r.export(0)
+    parity = bool(np.array_equal(rp, c3.mats[0][0]) and np.array_equal(col[:4096], c3.mats[0][1][:4096]) and np.array_equal(val[-4096:], c3.mats[0][2][-4096:]))
+    nnz = int(sum(c3.r.nnz))
+    return {"workload": f"arithCircuitToGenQAP at 2^{c3.log_n} gates ({c3.field} Fr): acx_circuit_create + acx_circuit_to_r1cs, m = {c3.r.m} wires, {nnz} entries",
+            "circuit_create_s": c3.t["circuit_create_s"], "to_r1cs_s": c3.t["to_r1cs_s"],
+            "constraints_per_s": n / (c3.t["circuit_create_s"] + c3.t["to_r1cs_s"]), "host_threads": effective_cpus(),
+            "synthetic_generation_s": c3.t["synth_and_create_s"], "export_matches_host_rows": parity,
+            "note": "wall clock of two C-ABI calls, host cores + one H2D of the rows; synthetic_generation_s (numpy, not product code) is outside"}
+
+
+def bench_qap_h(ctx, stream, c3, reps=10, prewarm=0.25):
     """configs[2]'s third C3 metric: the h(x) pipeline of verificationWitness (src/QAP.hs:309-327) on a
     2^20-constraint mulgraph system, device resident (witness in, N+1 coefficients out): residual dots,
     3 iNTT, 2 coset NTT (L, R), pointwise, coset iNTT, minus O / z in coefficient form -- six transforms.
     Parity gate: every coefficient against the C oracle (which runs the textbook seven)."""
     from oracle.c_oracle import COracle
+    field, log_n = c3.field, c3.log_n
     orc = COracle(field)
     n = 1 << log_n
-    s = synth.mulgraph(n, seed=0xAC3, field=field)
-    mats, w = s.rows(), s.witness()
-    r = s.circuit.to_r1cs(ctx)
-    dw = to_dev(ctx, w)
+    mats, w, r, dw = c3.mats, c3.w, c3.r, c3.dw
     dh = torch.zeros((n + 1, 4), dtype=torch.int64, device="cuda")
     res = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
@@ -258,7 +471,139 @@ def bench_qap_h(ctx, stream, field="bn254", log_n=20, reps=10, prewarm=0.25):
     alg = 7 * 128 * n + (b_r1cs + 3 * 32 * n) + 5 * 32 * n     # SURVEY.md 8(d)'s definition of the job: 7 NTTs + residual-style dots (written) + pointwise
     ops = 6 * (1.5 * n * log_n) + 4 * n + nnz + 2 * n           # butterflies of the SIX transforms actually run, scalings, dot-product MACs, pointwise + O / z
     return {"workload": f"verificationWitness h(x), 2^{log_n}-constraint mulgraph ({field} Fr), device resident: residual dots (1/z, -1/z riding on them) + 6 NTTs (O stays in coefficient form; the last one takes L*R on load and adds -O/z on store)", "transforms": 6,
-            "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6, "roofline": _hbm(alg, us)}
+            "parity_vs_oracle": parity, "us": us, "field_ops_per_s": ops / us * 1e6, "constraints_per_s": n / us * 1e6, "roofline": _hbm(alg, us)}
+
+
+def bench_qap_columns(ctx, stream, c3, prewarm=0.1):
+    """`createPolynomialsFFT` (src/QAP.hs:512-525) at 2^20 constraints, results left on the device (acx_qap_columns_dev): sparse
+    columns (intermediate wires: one entry in C, one or two in A -- interpolated directly, k_col_direct: k products per
+    coefficient) and dense columns (input wires, hundreds of entries: scatter + batched inverse NTT).  The kernel only stores:
+    bytes written / time against the HBM peak.  Parity gate: one sparse column of A, one of C and one dense column of A, every
+    coefficient and the stripped length, against the C oracle's interpolation."""
+    from oracle.c_oracle import COracle
+    orc = COracle(c3.field)
+    n, log_n, r = 1 << c3.log_n, c3.log_n, c3.r
+    wires = 64
+    out = torch.empty((wires * n, 4), dtype=torch.int64, device="cuda")
+    lens = torch.zeros(wires, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    mid0 = 1 + c3.s.n_in + n // 2
+    res, parity = {}, True
+    for what, w0, mat, cnt in (("sparse_A", mid0, 0, wires), ("sparse_C", mid0, 2, wires), ("dense_A", 1, 0, 16)):
+        r.qap_columns_dev(mat, w0, cnt, out.data_ptr(), lens.data_ptr())
+        ctx.sync()
+        want = orc.qap_columns(n, log_n, c3.mats[mat], w0 + 3, 1, nthreads=effective_cpus())[0]          # column 3 of the batch
+        got = _from_dev(ctx, out[3 * n:4 * n], n)
+        nz = np.nonzero(want.any(axis=1))[0]
+        parity = parity and bool(np.array_equal(got, want) and int(lens[3]) == (int(nz[-1]) + 1 if nz.size else 0))
+        us = _timed(stream, lambda: r.qap_columns_dev(mat, w0, cnt, out.data_ptr(), lens.data_ptr()), 5, prewarm)
+        rp = c3.mats[mat][0]
+        res[what] = {"columns_per_call": cnt, "us_per_column": us / cnt, "columns_per_s": cnt / us * 1e6,
+                     "roofline": _hbm(32 * n, us / cnt, note="store-only: 32 N bytes written per column")}
+    # entries per sparse column of the timed batches (what k_col_direct's cost follows)
+    colc = np.bincount(c3.mats[0][1], minlength=r.m)[mid0:mid0 + wires]
+    res["sparse_A"]["entries_per_column_mean"] = float(colc.mean())
+    return {"workload": f"createPolynomialsFFT at N = 2^{log_n} ({c3.field} Fr), acx_qap_columns_dev, {wires} sparse / 16 dense columns per call, results device resident",
+            "parity_vs_oracle": parity, **res,
+            "note": "sparse columns are VALU-issue bound (one shared Montgomery reduction + 81 multiplier instructions per entry and coefficient: "
+                    "~257 VALU instructions per 32 bytes at k = 1), not store bound: a plain store stream reaches 6.3-6.7 TB/s (tools/microbench/write_bw.hip)"}
+
+
+def _hip_runtime():
+    """the libamdhip64 this process already has mapped (torch's), for hipHostRegister on caller-owned numpy memory"""
+    import ctypes
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return ctypes.CDLL(line.split()[-1])
+    return ctypes.CDLL("libamdhip64.so")
+
+
+class Pinned:
+    """hipHostRegister on a numpy array for the life of a `with` block: what a host does once for a witness buffer it reuses"""
+
+    def __init__(self, arr):
+        self.arr, self.hip = arr, _hip_runtime()
+
+    def __enter__(self):
+        import ctypes
+        rc = self.hip.hipHostRegister(ctypes.c_void_p(self.arr.ctypes.data), ctypes.c_size_t(self.arr.nbytes), ctypes.c_uint(0))
+        if rc != 0:
+            raise RuntimeError(f"hipHostRegister failed ({rc})")
+        return self.arr
+
+    def __exit__(self, *exc):
+        import ctypes
+        self.hip.hipHostUnregister(ctypes.c_void_p(self.arr.ctypes.data))
+
+
+def bench_e2e(r, w, c3=None, many=48):
+    """SURVEY.md 8(d) "end-to-end incl. witness H2D": the HOST-BUFFER boundary the reference's callers use
+    (`verifyAssignment qap assignment`, src/QAP.hs:276-282) -- acx_r1cs_verify on a canonical witness in host memory: H2D copy,
+    canonicity check + Montgomery conversion, the residual launch, the verdict back -- on one 2^16-constraint system of the
+    headline workload: pageable and hipHostRegister-ed witness, one caller and four concurrent callers (four lanes per
+    context), and acx_r1cs_verify_many (`all (verifyAssignment qap) inputs`: one copy + one batched launch per chunk).
+    PCIe-inclusive constraints/s: never the headline `value`.  Every call must accept the satisfying witness."""
+    import threading
+    n, m = r.n, r.m
+    out = {"workload": f"acx_r1cs_verify / acx_r1cs_verify_many on host buffers: one 2^{n.bit_length() - 1}-constraint system, witness {m * 32 / 1e6:.2f} MB per call"}
+
+    def rate(rows, fn, reps, callers=1):
+        for _ in range(3):
+            fn()
+        if callers == 1:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return rows * reps / (time.perf_counter() - t0)
+        bar = threading.Barrier(callers + 1)
+
+        def body():
+            bar.wait()
+            for _ in range(reps):
+                fn()
+            bar.wait()
+        th = [threading.Thread(target=body) for _ in range(callers)]
+        for t in th:
+            t.start()
+        bar.wait()
+        t0 = time.perf_counter()
+        bar.wait()
+        dt = time.perf_counter() - t0
+        for t in th:
+            t.join()
+        return rows * reps * callers / dt
+
+    def one(sys_, wv):
+        assert sys_.verify(wv)[0], "host-buffer verify rejected a satisfying witness"
+
+    wp = w.copy()
+    out["verify_pageable"] = {"constraints_per_s": rate(n, lambda: one(r, w), 100), "callers": 1}
+    out["verify_pageable_4_callers"] = {"constraints_per_s": rate(n, lambda: one(r, w), 50, 4), "callers": 4}
+    with Pinned(wp):
+        out["verify_pinned"] = {"constraints_per_s": rate(n, lambda: one(r, wp), 100), "callers": 1}
+        out["verify_pinned_4_callers"] = {"constraints_per_s": rate(n, lambda: one(r, wp), 50, 4), "callers": 4}
+    W = np.ascontiguousarray(np.broadcast_to(w, (many,) + w.shape))
+
+    def vm(buf):
+        ok, _, _ = r.verify_many(buf)
+        assert ok.all(), "verify_many rejected a satisfying witness"
+
+    vm(W)
+    t0 = time.perf_counter(); vm(W); vm(W); dt = (time.perf_counter() - t0) / 2
+    out["verify_many_pageable"] = {"witnesses": many, "constraints_per_s": n * many / dt, "host_GB_per_s": W.nbytes / dt * 1e-9}
+    with Pinned(W):
+        vm(W)
+        t0 = time.perf_counter(); vm(W); vm(W); dt = (time.perf_counter() - t0) / 2
+        out["verify_many_pinned"] = {"witnesses": many, "constraints_per_s": n * many / dt, "host_GB_per_s": W.nbytes / dt * 1e-9}
+    if c3 is not None:          # configs[2]'s size: 33 MB of witness per call
+        big = {"workload": f"the same on the 2^{c3.log_n}-constraint system: witness {c3.r.m * 32 / 1e6:.1f} MB per call",
+               "verify_pageable": {"constraints_per_s": rate(c3.r.n, lambda: one(c3.r, c3.w), 10)}}
+        w2 = c3.w.copy()
+        with Pinned(w2):
+            big["verify_pinned"] = {"constraints_per_s": rate(c3.r.n, lambda: one(c3.r, w2), 10)}
+        out["configs2"] = big
+    out["note"] = "PCIe-inclusive wall clock per blocking C-ABI call (H2D + conversion + launch + verdict D2H); the device-resident launch is the headline"
+    return out
 
 
 def bench_small_coeff(ctx, stream, field="bn254", copies=32, log_n=16, reps=50, prewarm=0.25):

@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
 """Same-box A/B of builds of libacx.so (tools/build_variant.py) on bench.py's secondary objects: alternating processes,
 `rounds` rounds, both fields on request; prints the 2^20 NTT, the batch-of-64 NTT per transform, h(x) at 2^20 and the
-headline launch, in us.   python tools/lib_ab.py [--rounds 2] [--fields bn254 bls12_381] NAME=path/to/libacx_NAME.so ..."""
+headline launch, in us.   python tools/lib_ab.py [--rounds 2] [--fields bn254,bls12_381] NAME=path/to/libacx_NAME.so ..."""
 import argparse, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=2)
-ap.add_argument("--fields", nargs="*", default=["bn254"])
+ap.add_argument("--fields", default="bn254", help="comma separated: bn254,bls12_381")
 ap.add_argument("variants", nargs="+")
 a = ap.parse_args()
 rows = {}
 for rnd in range(a.rounds):
-    for field in a.fields:
+    for field in a.fields.split(","):
         for v in a.variants:
             name, _, path = v.partition("=")
             env = dict(os.environ, ACX_LIB=os.path.abspath(path))
