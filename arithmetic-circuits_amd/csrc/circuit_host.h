@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstdlib>
 #include <exception>
@@ -296,55 +297,111 @@ public:
         });
     }
 
-    void build_rows_range(uint64_t g_begin, uint64_t g_end, HostCsr& A, HostCsr& B, HostCsr& C) const {
+    // gateToGenQAP of ONE gate (src/QAP.hs:366-474): its rows as {A, B, C} maps column -> value holding EVERY wire the
+    // reference's row mentions -- the constant, the updated wires, explicit zeros included.  The zeros are void while roots are
+    // distinct (push_row drops them); they decide what survives when two rows share a root (build_rows_reference).
+    using RowMaps = std::array<std::map<uint64_t, H256>, 3>;
+    void gate_rows(uint64_t g, std::vector<RowMaps>& rows) const {
         const H256 one = hf.one(), minus_one = hf.neg(hf.one()), zero = hf.zero();
-        for (uint64_t g = g_begin; g < g_end; ++g) {
-            const acx_wire* gw = &wires[wire_ofs[g]];
-            if (kind[g] == ACX_GATE_MUL) {
-                std::map<uint64_t, H256> l, r, o;
-                H256 lc, rc;
-                affine_map(tok_ofs[2 * g], tok_ofs[2 * g + 1], lc, l);
-                affine_map(tok_ofs[2 * g + 1], tok_ofs[2 * g + 2], rc, r);
-                l[0] = lc;  // constantQapSet (root, leftInputConst): a Var can never name column 0
-                r[0] = rc;
-                o[flat(gw[0])] = one;
-                A.push_row(hf, l); B.push_row(hf, r); C.push_row(hf, o);
-            } else if (kind[g] == ACX_GATE_EQUAL) {
-                const uint64_t i = flat(gw[0]), mg = flat(gw[1]), out = flat(gw[2]);
-                auto set3 = [&](H256 vi, H256 vm, H256 vo, H256 cst) {
-                    std::map<uint64_t, H256> row;
-                    row[0] = cst;
-                    row[i] = vi; row[mg] = vm; row[out] = vo;  // updateAtWires: later entries overwrite
-                    return row;
-                };
-                A.push_row(hf, set3(one, zero, zero, zero));       // row0: i * m = out
-                B.push_row(hf, set3(zero, one, zero, zero));
-                C.push_row(hf, set3(zero, zero, one, zero));
-                A.push_row(hf, set3(zero, zero, minus_one, one));  // row1: (1 - out) * i = 0
-                B.push_row(hf, set3(one, zero, zero, zero));
-                C.push_row(hf, set3(zero, zero, zero, zero));
-            } else {
-                const uint64_t n_outs = wire_ofs[g + 1] - wire_ofs[g] - 1;
-                const uint64_t inp = flat(gw[0]);
-                std::map<uint64_t, H256> a0, b0, c0;
-                a0[0] = zero; a0[inp] = zero;
-                H256 pw = one;  // 2^j
-                for (uint64_t j = 0; j < n_outs; ++j) {
-                    a0[flat(gw[1 + j])] = pw;
-                    pw = hf.add(pw, pw);
-                }
-                b0[0] = one; b0[inp] = zero;
-                c0[0] = zero; c0[inp] = one;
-                A.push_row(hf, a0); B.push_row(hf, b0); C.push_row(hf, c0);
-                for (uint64_t j = 0; j < n_outs; ++j) {  // bit * (1 - bit) = 0
-                    const uint64_t o = flat(gw[1 + j]);
-                    std::map<uint64_t, H256> a, b, c;
-                    a[0] = zero; a[o] = one;
-                    b[0] = one; b[o] = minus_one;
-                    A.push_row(hf, a); B.push_row(hf, b); C.push_row(hf, c);
-                }
+        const acx_wire* gw = &wires[wire_ofs[g]];
+        rows.clear();
+        if (kind[g] == ACX_GATE_MUL) {
+            rows.emplace_back();
+            auto& l = rows[0][0]; auto& r = rows[0][1]; auto& o = rows[0][2];
+            H256 lc, rc;
+            affine_map(tok_ofs[2 * g], tok_ofs[2 * g + 1], lc, l);
+            affine_map(tok_ofs[2 * g + 1], tok_ofs[2 * g + 2], rc, r);
+            l[0] = lc;  // constantQapSet (root, leftInputConst): a Var can never name column 0
+            r[0] = rc;
+            o[0] = zero;
+            o[flat(gw[0])] = one;
+        } else if (kind[g] == ACX_GATE_EQUAL) {
+            const uint64_t i = flat(gw[0]), mg = flat(gw[1]), out = flat(gw[2]);
+            auto set3 = [&](H256 vi, H256 vm, H256 vo, H256 cst) {
+                std::map<uint64_t, H256> row;
+                row[0] = cst;
+                row[i] = vi; row[mg] = vm; row[out] = vo;  // updateAtWires: later entries overwrite
+                return row;
+            };
+            rows.resize(2);
+            rows[0] = {set3(one, zero, zero, zero), set3(zero, one, zero, zero), set3(zero, zero, one, zero)};      // row0: i * m = out
+            rows[1] = {set3(zero, zero, minus_one, one), set3(one, zero, zero, zero), set3(zero, zero, zero, zero)}; // row1: (1 - out) * i = 0
+        } else {
+            const uint64_t n_outs = wire_ofs[g + 1] - wire_ofs[g] - 1;
+            const uint64_t inp = flat(gw[0]);
+            rows.resize(1 + n_outs);
+            auto& a0 = rows[0][0]; auto& b0 = rows[0][1]; auto& c0 = rows[0][2];
+            a0[0] = zero; a0[inp] = zero;
+            H256 pw = one;  // 2^j
+            for (uint64_t j = 0; j < n_outs; ++j) {
+                a0[flat(gw[1 + j])] = pw;
+                pw = hf.add(pw, pw);
+            }
+            b0[0] = one; b0[inp] = zero;
+            c0[0] = zero; c0[inp] = one;
+            for (uint64_t j = 0; j < n_outs; ++j) {  // bit * (1 - bit) = 0
+                const uint64_t o = flat(gw[1 + j]);
+                auto& a = rows[1 + j][0]; auto& b = rows[1 + j][1]; auto& c = rows[1 + j][2];
+                a[0] = zero; a[o] = one;
+                b[0] = one; b[o] = minus_one;
+                c[0] = zero; c[o] = zero;
             }
         }
+    }
+
+    void build_rows_range(uint64_t g_begin, uint64_t g_end, HostCsr& A, HostCsr& B, HostCsr& C) const {
+        std::vector<RowMaps> rows;
+        for (uint64_t g = g_begin; g < g_end; ++g) {
+            gate_rows(g, rows);
+            for (const auto& r : rows) { A.push_row(hf, r[0]); B.push_row(hf, r[1]); C.push_row(hf, r[2]); }
+        }
+    }
+
+    // `arithCircuitToGenQAP rootsPerGate circuit` (src/QAP.hs:530-539) on ANY root lists, exactly as the reference computes it:
+    //   zipWith gateToGenQAP rootsPerGate gates     lists beyond the last gate make no rows, gates beyond the last list are
+    //                                               dropped; a list of the wrong length for its gate is the reference's panic
+    //                                               (src/QAP.hs:444-445,474) = ACX_ERR_ROOT_COUNT
+    //   createMapGenQap (src/QAP.hs:233-239)        per wire `Map.fromList` over the rows in order: of two rows with the SAME
+    //                                               root the later one wins on every wire it mentions (explicit zeros and the
+    //                                               constant included), wires it does not mention keep the earlier row's value
+    //   addMissingZeroes (concat rootsPerGate)      every root of every list owns a row; roots no gate wrote are zero rows
+    // roots: the lists concatenated (canonical); counts[g] = length of list g.  Out: one row per DISTINCT root, ascending
+    // (`Map.elems`, src/QAP.hs:521-523), and those roots.  Sequential and map-based: degenerate lists are small.
+    int build_rows_reference(const acx_fr* roots, const uint32_t* counts, uint64_t n_lists, HostCsr out[3], std::vector<H256>& distinct,
+                             std::string& msg) const {
+        const uint64_t used = std::min<uint64_t>(n_lists, n_gates);
+        uint64_t total = 0;
+        for (uint64_t g = 0; g < n_lists; ++g) {
+            if (g < used && counts[g] != rows_of_gate(g)) { msg = "gateToGenQAP: wrong number of roots supplied"; return ACX_ERR_ROOT_COUNT; }
+            total += counts[g];
+        }
+        if (total && !roots) { msg = "null root array"; return ACX_ERR_INVALID_ARG; }
+        std::vector<H256> rv(total);
+        for (uint64_t i = 0; i < total; ++i) {
+            std::memcpy(rv[i].l, roots[i].b, 32);
+            if (!hf.is_canonical(rv[i])) { msg = "root >= p"; return ACX_ERR_NONCANONICAL; }
+        }
+        auto less = [](const H256& a, const H256& b) { return h256_cmp(a, b) < 0; };
+        distinct = rv;
+        std::sort(distinct.begin(), distinct.end(), less);
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        std::vector<std::map<uint64_t, H256>> merged[3];
+        for (auto& mk : merged) mk.resize(distinct.size());
+        std::vector<RowMaps> rows;
+        uint64_t pos = 0;
+        for (uint64_t g = 0; g < used; ++g) {
+            gate_rows(g, rows);
+            for (const auto& r : rows) {
+                const uint64_t ri = (uint64_t)(std::lower_bound(distinct.begin(), distinct.end(), rv[pos++], less) - distinct.begin());
+                for (int k = 0; k < 3; ++k)
+                    for (const auto& kv : r[k]) merged[k][ri][kv.first] = kv.second;       // Map.fromList: the later pair wins
+            }
+        }
+        for (int k = 0; k < 3; ++k) {
+            out[k] = HostCsr();
+            for (const auto& row : merged[k]) out[k].push_row(hf, row);
+        }
+        return ACX_OK;
     }
 
     // generateAssignment.  inputs canonical.  Returns ACX_OK / ACX_ERR_UNDEFINED_WIRE.

@@ -1766,6 +1766,83 @@ int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots,
     return guarded([&]() -> int { return circuit_to_r1cs_impl(ctx, c, roots, n_roots, out); });
 }
 
+// `arithCircuitToGenQAP rootsPerGate circuit` with the roots as the reference takes them, one list PER GATE.
+// Lists that are one-per-gate, of the right lengths and pairwise distinct are the ordinary case: the flat call.  Anything else
+// is an error without ACX_ROOTS_REFERENCE_SEMANTICS and the reference's own result with it (HostCircuit::build_rows_reference).
+static int lists_are_regular(const HostCircuit& hc, const acx_fr* roots, const uint32_t* counts, uint64_t n_lists, bool* regular) {
+    *regular = false;
+    if (n_lists != hc.n_gates) return ACX_OK;
+    uint64_t total = 0;
+    for (uint64_t g = 0; g < n_lists; ++g) {
+        if (counts[g] != hc.rows_of_gate(g)) return ACX_OK;
+        total += counts[g];
+    }
+    if (total && !roots) return fail(ACX_ERR_INVALID_ARG, "null root array");
+    std::vector<H256> rv(total);
+    for (uint64_t i = 0; i < total; ++i) std::memcpy(rv[i].l, roots[i].b, 32);
+    std::sort(rv.begin(), rv.end(), [](const H256& a, const H256& b) { return h256_cmp(a, b) < 0; });
+    *regular = std::adjacent_find(rv.begin(), rv.end()) == rv.end();
+    return ACX_OK;
+}
+
+int acx_circuit_rows_lists(const acx_circuit* c, const acx_fr* roots, const uint32_t* counts, uint64_t n_lists, uint32_t flags, int matrix,
+                           uint64_t* n_rows, uint64_t* nnz, uint32_t* rowptr, uint32_t* col, acx_fr* val, acx_fr* sorted_roots) {
+    if (!c || matrix < 0 || matrix > 2 || (n_lists && !counts)) return fail(ACX_ERR_INVALID_ARG, "bad argument");
+    if (flags & ~(uint32_t)ACX_ROOTS_REFERENCE_SEMANTICS) return fail(ACX_ERR_INVALID_ARG, "unknown flag");
+    return guarded([&]() -> int {
+        if (!(flags & ACX_ROOTS_REFERENCE_SEMANTICS)) {
+            ACX_TRY(acx_circuit_check_root_counts(c, counts, n_lists));
+            uint64_t total = 0;
+            for (uint64_t g = 0; g < n_lists; ++g) total += counts[g];
+            std::vector<uint64_t> order;
+            ACX_TRY(root_order(c->hc, roots, total, order));       // ACX_ERR_DUPLICATE_ROOT on a repeated root
+        }
+        HostCsr M[3];
+        std::vector<H256> distinct;
+        std::string msg;
+        const int rc = c->hc.build_rows_reference(roots, counts, n_lists, M, distinct, msg);
+        if (rc != ACX_OK) return fail(rc, msg);
+        const HostCsr& src = M[matrix];
+        if (n_rows) *n_rows = distinct.size();
+        if (nnz) *nnz = src.col.size();
+        if (rowptr) std::memcpy(rowptr, src.rowptr.data(), src.rowptr.size() * 4);
+        if (col && !src.col.empty()) std::memcpy(col, src.col.data(), src.col.size() * 4);
+        if (val && !src.val.empty()) std::memcpy(val, src.val.data(), src.val.size() * 32);
+        if (sorted_roots && !distinct.empty()) std::memcpy(sorted_roots, distinct.data(), distinct.size() * 32);
+        return ACX_OK;
+    });
+}
+
+int acx_circuit_to_r1cs_lists(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, const uint32_t* counts, uint64_t n_lists,
+                              uint32_t flags, acx_r1cs** out) {
+    if (!ctx || !c || !out || (n_lists && !counts)) return fail(ACX_ERR_INVALID_ARG, "null argument");
+    if (c->field != ctx->field) return fail(ACX_ERR_INVALID_ARG, "circuit and context are over different fields");
+    if (flags & ~(uint32_t)ACX_ROOTS_REFERENCE_SEMANTICS) return fail(ACX_ERR_INVALID_ARG, "unknown flag");
+    return guarded([&]() -> int {
+        bool regular = false;
+        ACX_TRY(lists_are_regular(c->hc, roots, counts, n_lists, &regular));
+        uint64_t total = 0;
+        for (uint64_t g = 0; g < n_lists; ++g) total += counts[g];
+        if (regular) return circuit_to_r1cs_impl(ctx, c, roots, total, out);      // the ordinary path: rows of the circuit, evaluation plan kept
+        if (!(flags & ACX_ROOTS_REFERENCE_SEMANTICS)) {
+            ACX_TRY(acx_circuit_check_root_counts(c, counts, n_lists));
+            std::vector<uint64_t> order;
+            return root_order(c->hc, roots, total, order);                            // reports the duplicate / the bad element
+        }
+        HostCsr M[3];
+        std::vector<H256> distinct;
+        std::string msg;
+        const int rc = c->hc.build_rows_reference(roots, counts, n_lists, M, distinct, msg);
+        if (rc != ACX_OK) return fail(rc, msg);
+        acx_csr views[3];
+        for (int k = 0; k < 3; ++k) views[k] = acx_csr{M[k].rowptr.data(), M[k].col.data(), reinterpret_cast<const acx_fr*>(M[k].val.data())};
+        const acx_csr* mats[3] = {&views[0], &views[1], &views[2]};
+        // no evaluation plan: the rows no longer correspond to gates one to one (acx_r1cs_eval reports ACX_ERR_UNSUPPORTED;
+        // acx_circuit_eval is the reference's own host fold)
+        return r1cs_from_host(ctx, distinct.size(), c->hc.m(), mats, out);
+    });
+}
+
 // ---------------------------------------------------------------------------------- R1CS
 int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C,
                   acx_r1cs** out) {

@@ -38,6 +38,8 @@ PHASES = {}
 def guard(where, fn, *args, **kw):
     t0 = time.perf_counter()
     try:
+        if os.environ.get("ACX_BENCH_FAIL") == where:       # test hook: what a failing secondary measurement does to the line
+            raise RuntimeError("injected failure (ACX_BENCH_FAIL)")
         return fn(*args, **kw)
     except BaseException as e:                      # AssertionError of a parity gate included
         if isinstance(e, (KeyboardInterrupt, SystemExit)):
@@ -111,7 +113,7 @@ def measure_traffic_live(a):
     return None if r is None else (r[0] / r[1] * 1024.0 * 2.0, r[1])
 
 
-def cpu_baseline(sample, field="bn254", budget_s=12.0):
+def cpu_baseline(sample, field="bn254", budget_s=12.0, with_reference_algorithm=True):
     """The CPU restatement (oracle/acx_oracle.c, "port") timed on this host's cores on a bounded
     sample of the same workload: one 2^16-constraint system verified `repeat` times per call
     (threads persist across the repeats of a call), calls repeated for ~budget_s seconds."""
@@ -133,7 +135,8 @@ def cpu_baseline(sample, field="bn254", budget_s=12.0):
            "sample": f"{calls * repeat} x verifyAssignment of one 2^{n.bit_length() - 1}-constraint system "
                      f"(oracle/acx_oracle.c, {threads} pthreads = the CPUs this process may use: {os.cpu_count()} hardware threads visible, "
                      f"cgroup quota applied; {dt:.1f} s)"}
-    out["reference_algorithm"] = cpu_reference_algorithm(orc, field)
+    if with_reference_algorithm:
+        out["reference_algorithm"] = cpu_reference_algorithm(orc, field)
     return out
 
 
@@ -641,6 +644,66 @@ def bench_small_coeff(ctx, stream, field="bn254", copies=32, log_n=16, reps=50, 
             "algorithmic_bytes_as_8d": alg, "note": "8 bytes per entry are streamed instead of 40; not an HBM-roofline figure"}
 
 
+def bench_field_subrun(field, device, copies, log_n, prewarm, c3_future):
+    """BASELINE.json configs[4] (the field swap: BLS12-381 Fr) observed in the SAME run as the headline: the batched
+    verification launch of the headline workload over that field (same generator, same seeds), one 2^20-point transform and
+    h(x) of a 2^20-constraint system, each parity-gated against the C oracle like the headline's own objects."""
+    from oracle.c_oracle import COracle
+    orc = COracle(field)
+    ctx = acx.Context(field, device)
+    stream = torch.cuda.ExternalStream(ctx.stream)
+    n = 1 << log_n
+    systems, witnesses, alg = [], [], 0
+    for c in range(copies):
+        s = synth.mulgraph(n, seed=0xAC355 + c, field=field)
+        w = s.witness()
+        systems.append(s.circuit.to_r1cs(ctx))
+        witnesses.append(to_dev(ctx, w))
+        if c == 0:
+            mats0, w0 = s.rows(), w
+        alg += algorithmic_bytes(s.rows(), n)[0]
+    res = torch.tensor([0, -1], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    batch = acx.Batch(ctx, systems, [w.data_ptr() for w in witnesses], res.data_ptr())
+    us = _timed(stream, batch.verify_dev, 30, prewarm)
+    ctx.sync()
+    accepted = int(res[0]) == 0
+    wb = w0.copy()
+    wb[77, 0] ^= np.uint64(1)
+    want_res, want_bad, want_first = orc.r1cs_residuals(n, systems[0].m, *mats0, wb, nthreads=effective_cpus())
+    parity = bool(accepted and want_bad > 0 and np.array_equal(systems[0].residuals(wb), want_res) and systems[0].verify(wb) == (False, want_bad, want_first))
+    out = {"config": f"configs[4]: the field swap -- {field} Fr on the headline workload ({copies} x 2^{log_n}-constraint mulgraph systems per launch) and on configs[2]'s 2^20 sizes",
+           "r1cs_verify": {"us_per_launch": us, "constraints_per_s": copies * n / us * 1e6, "parity_vs_oracle": parity,
+                           "roofline": _hbm(alg, us, kernel="acx::k_r1cs_sell_split<Bls12381Fr>" if field == "bls12_381" else "acx::k_r1cs_sell_split<Bn254Fr>")}}
+    del batch
+    systems.clear(); witnesses.clear()
+    out["ntt"] = bench_ntt(ctx, stream, field, prewarm=prewarm, batch=0)
+    c3 = c3_future.result().load(ctx)
+    out["qap_h"] = bench_qap_h(ctx, stream, c3, reps=5, prewarm=prewarm)
+    return out
+
+
+def run_with_deadline(fn, seconds, device):
+    """fn() on a helper thread with a deadline: a collective that one rank never joins blocks inside the runtime and cannot be
+    interrupted -- the line (already holding the headline value) must still be printed.  Returns (result, None) or
+    (None, "timeout") / (None, error text); after a timeout the caller prints its line and leaves with os._exit."""
+    import threading
+    box = {}
+
+    def body():
+        try:
+            torch.cuda.set_device(device)
+            box["r"] = fn()
+        except BaseException as e:
+            box["e"] = (type(e).__name__ + ": " + str(e))[:400]
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, "timeout"
+    return box.get("r"), box.get("e")
+
+
 def bench_distributed(ctx, a, world, rank, dist):
     """configs[3] beside the headline (N > 1, or --force-dist on one GPU): the distributed four-step NTT at
     N = 2^24 (one all-to-all per transform) and the distributed h(x) pipeline on a 2^24-constraint block system
@@ -649,6 +712,8 @@ def bench_distributed(ctx, a, world, rank, dist):
     code path at 2^16; the pipeline must accept the satisfying witness and reject a corrupted one."""
     par = importlib.import_module("arithmetic-circuits_amd.parallel")
     from oracle.c_oracle import COracle
+    if os.environ.get("ACX_BENCH_HANG_DIST") == "1" and rank == world - 1:     # test hook: one rank never joins the collectives
+        time.sleep(1e6)
     orc = COracle(a.field)
     ops = par.HipOps(ctx)
     coll = None                                      # the product's collectives: torch.distributed over RCCL
@@ -802,7 +867,8 @@ def main_mgpu(a, devices):
                          traffic=None, traffic_measured_in_run=False),
     }
     ln = (bs.n - 1).bit_length()
-    if not a.no_dist_pipeline and mr.n == 1 << ln and ln <= 24:
+
+    def qap_h_resident():
         mr.upload_witness(w)                           # the parity gate above left the corrupted witness resident
         ok = mr.qap_h_resident()                       # first call: buffers, tables
         t1 = time.perf_counter()
@@ -813,9 +879,22 @@ def main_mgpu(a, devices):
         sec = (time.perf_counter() - t1) / reps
         mr.upload_witness(wb)
         ok_bad = mr.qap_h_resident()
-        out["mgpu_qap_h"] = {"workload": f"acx_mgpu_qap_h_resident: verificationWitness h(x) of the same 2^{ln}-constraint system over {W} shard(s): "
-                                         f"block-cyclic rows, 6 all-to-alls + 1 all-reduce per call, blocking call",
-                             "accepts_valid_rejects_corrupt": bool(ok and not ok_bad), "us": sec * 1e6, "constraints_per_s": bs.n / sec}
+        return {"workload": f"acx_mgpu_qap_h_resident: verificationWitness h(x) of the same 2^{ln}-constraint system over {W} shard(s): "
+                            f"block-cyclic rows, 6 all-to-alls + 1 all-reduce per call, blocking call",
+                "accepts_valid_rejects_corrupt": bool(ok and not ok_bad), "us": sec * 1e6, "constraints_per_s": bs.n / sec}
+
+    if a.want("dist") and mr.n == 1 << ln and ln <= 24:
+        r = guard("mgpu_qap_h", qap_h_resident)
+        if r is not None:
+            out["mgpu_qap_h"] = r
+    if a.want("cpu"):           # the same CPU baseline as the one-process-per-GPU line: one block of this system on the host's cores
+        r = guard("cpu", cpu_baseline, (bs.mats, np.concatenate([w[:1], w[-(bs.m0 - 1):]]), n0, bs.m0), a.field, 10.0, True)
+        if r is not None:
+            out["cpu_baseline"] = r
+    if ERRORS:
+        out["errors"] = ERRORS
+    PHASES["total"] = round(time.perf_counter() - T_START, 3)
+    out["phases_s"] = PHASES
     mr.close()
     mg.close()
     sys.stdout.flush()
@@ -845,12 +924,24 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE pass (roofline.traffic then comes from profiles/r03_traffic.json, flagged)")
     ap.add_argument("--only-steps", action="store_true", help="internal: nothing but the batched launches (the child of the PMC pass)")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--only-ntt", action="store_true", help="internal: nothing but 40 single 2^20-point transforms (the child of the NTT counter pass)")
+    ap.add_argument("--skip", default="", help="comma list of secondary objects to skip: pmc,ntt,qap_h,small,ref,load,cols,e2e,field2,cpu,dist or all")
+    ap.add_argument("--only", default="", help="comma list of secondary objects to run (the rest is skipped)")
+    ap.add_argument("--dist-deadline", type=float, default=240.0, help="seconds the distributed extras of a multi-rank run may take before the line is printed without them")
     ap.add_argument("--launcher", default="auto", choices=["auto", "ranks", "mgpu"],
                     help="ranks: one process per GPU (torch.distributed.run, what the driver uses); mgpu: ONE process, all GPUs "
                          "through acx_mgpu_*; auto: mgpu when --gpus N > 1 is asked for outside torch.distributed.run")
     ap.add_argument("--mgpu-devices", default=None,
                     help="device ordinals of the mgpu launcher, e.g. 0,1,2,3 or 0,0 (repeats = several shards on one GPU); default 0..N-1")
     a = ap.parse_args()
+    skip, only = set(filter(None, a.skip.split(","))), set(filter(None, a.only.split(",")))
+    if a.no_cpu: skip.add("cpu")
+    if a.no_pmc: skip.add("pmc")
+    if a.no_ntt: skip |= {"ntt", "qap_h", "small", "load", "cols"}
+    if a.no_dist_pipeline: skip.add("dist")
+    a.want = lambda name: "all" not in skip and name not in skip and (not only or name in only)
+    if a.only_ntt:
+        return only_ntt(a)
     in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if a.launcher == "mgpu" or (a.launcher == "auto" and not in_torchrun and (a.gpus > 1 or a.mgpu_devices)):
         devices = [int(x) for x in a.mgpu_devices.split(",")] if a.mgpu_devices else list(range(a.gpus))
@@ -1037,15 +1128,28 @@ def main():
         assert int(res_r[0]) == 0, "cache-resident batch rejected a valid witness"
         del rb
 
+    PHASES["setup_and_headline"] = round(time.perf_counter() - T_START, 3)
+    per_rank_us = [kernel_us]
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
-    dist_extra = {}
-    if use_dist and not a.no_dist_pipeline:
+        allk = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(allk, torch.tensor([kernel_us], dtype=torch.float64, device="cuda"))
+        per_rank_us = [float(x[0]) for x in allk]
+    dist_extra, timed_out = {}, False
+    if use_dist and a.want("dist") and not a.only_steps:
         del batches, neg_batch
         systems.clear(); witnesses.clear()
-        dist_extra = bench_distributed(ctx, a, world, rank, dist)
+        # under a deadline: a rank that fails inside a collective leaves the others blocked in the runtime
+        t0 = time.perf_counter()
+        got, err = run_with_deadline(lambda: bench_distributed(ctx, a, world, rank, dist), a.dist_deadline, local_rank)
+        PHASES["dist"] = round(time.perf_counter() - t0, 3)
+        dist_extra = got or {}
+        if err:
+            ERRORS.append({"where": f"bench_distributed (rank {rank})", "error": err})
+            timed_out = err == "timeout"
+    line = None
     if rank == 0:
         total = world * a.copies * n * a.steps
         value = total / dt
@@ -1066,6 +1170,9 @@ def main():
                          "kernel": "acx::k_r1cs_sell_split", "kernel_us": kernel_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if world > 1:       # every rank's own launch time (each rank streams its own 32 systems): the per-rank roofline fractions
+            out["roofline"]["per_rank_kernel_us"] = per_rank_us
+            out["roofline"]["per_rank_frac"] = [bytes_per_launch / u * 1e-3 / HBM_PEAK_GBS for u in per_rank_us]
         if resident_us:
             out["cache_resident"] = {"us_per_launch": resident_us, "constraints_per_s": a.copies * n / resident_us * 1e6,
                                      "single_system_us_per_launch": single_us,
@@ -1078,54 +1185,14 @@ def main():
                                 "us_per_step_median": bs[len(bs) // 2], "us_per_step_min": bs[0], "us_per_step_max": bs[-1],
                                 "frac_median": bytes_per_launch / bs[len(bs) // 2] * 1e-3 / HBM_PEAK_GBS,
                                 "note": "kernel times at the sustained clock (0.25 s untimed pre-run before the timed region)"}
-        live = None
-        if world == 1 and not use_dist and not a.no_pmc and not a.only_steps:
-            live = measure_traffic_live(a)
-        if live is not None:
-            # HBM bytes of the headline kernel measured in THIS run: a rocprofv3 --pmc FETCH_SIZE pass of its own over the
-            # same batched launches in a child process (counters need the profiler around the process)
-            out["roofline"]["traffic"] = live[0]
-            out["roofline"]["traffic_measured_in_run"] = True
-            out["roofline"]["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE around a child run of this script's batched launches ({live[1]} launches "
-                                                 "averaged); bytes = FETCH_SIZE (KiB) * 1024 * 2 (gfx950 reports half of wide coalesced reads)")
-            out["roofline"]["achieved_traffic"] = live[0] / kernel_us * 1e-3
-            out["roofline"]["frac_traffic"] = out["roofline"]["achieved_traffic"] / HBM_PEAK_GBS
-        live_valu = measure_counter_live(a, "SQ_INSTS_VALU") if live is not None else None      # second pass, its own run
-        try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))["acx::k_r1cs_sell"]
-            if live is not None and tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
-                out["roofline"]["traffic_committed_pass"] = tr["traffic_bytes_per_launch"]       # the earlier pass, for comparison
-                out["roofline"]["valu_issue"] = _valu_issue("acx::k_r1cs_sell", "valu_wave_insts_per_launch", kernel_us, tr["workload"])
-                if live_valu is not None and out["roofline"]["valu_issue"]:
-                    # SQ_INSTS_VALU of this run instead of the committed pass (the issue RATE stays the microbenchmark's)
-                    vi = out["roofline"]["valu_issue"]
-                    vi["issue_bound_us"] *= live_valu[0] / vi["wave_insts"]
-                    vi["wave_insts"] = live_valu[0]
-                    vi["frac"] = vi["issue_bound_us"] / kernel_us
-                    vi["measured_in_run"] = True
-                    vi["source"] = "SQ_INSTS_VALU from a rocprofv3 --pmc pass of this run; issue rate from profiles/r01_valu_rates.txt"
-            elif tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}:
-                # NOT measured in this run: a constant from the committed rocprofv3 --pmc pass of the same command (PMC
-                # counters need the profiler around the process).  The live quantities of this line are the times.
-                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_measured_in_run"] = False
-                out["roofline"]["traffic_source"] = tr["source"]
-                out["roofline"]["traffic_measured_at_commit"] = tr.get("measured_at_commit")
-                # the same launch time against the bytes the kernel really moves (the algorithmic figure counts 36 bytes
-                # per C entry that the unit-C path never reads, and 36 instead of 40 per A / B entry)
-                out["roofline"]["achieved_traffic"] = tr["traffic_bytes_per_launch"] / kernel_us * 1e-3
-                out["roofline"]["frac_traffic"] = out["roofline"]["achieved_traffic"] / HBM_PEAK_GBS
-                out["roofline"]["valu_issue"] = _valu_issue("acx::k_r1cs_sell", "valu_wave_insts_per_launch", kernel_us, tr["workload"])
-        except (OSError, KeyError, ValueError):
-            pass
-        if world == 1 and not a.no_ntt:
-            out["ntt"] = bench_ntt(ctx, stream, a.field, prewarm=a.prewarm)
-            out["qap_h"] = bench_qap_h(ctx, stream, a.field, prewarm=a.prewarm)
-            out["r1cs_small_coeff"] = bench_small_coeff(ctx, stream, a.field, copies=a.copies, log_n=a.logn, prewarm=a.prewarm)
-        if world == 1 and not a.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(sample, a.field)
+        if not a.only_steps and not timed_out:
+            guard("secondary", secondary_objects, a, out, ctx, stream, world, use_dist, local_rank, systems, witnesses, sample, kernel_us)
+        if ERRORS:
+            out["errors"] = ERRORS
+        PHASES["total"] = round(time.perf_counter() - T_START, 3)
+        out["phases_s"] = PHASES
         line = json.dumps(out)
-    if use_dist:
+    if use_dist and not timed_out:
         dist.barrier()
         dist.destroy_process_group()
     # RCCL writes its version banner through C stdio, which a pipe buffers until exit: flush it first so that the JSON
@@ -1137,6 +1204,91 @@ def main():
         if world > 1:
             time.sleep(0.5)     # the other ranks have nothing left to do but flush and exit
         print(line, flush=True)
+    if timed_out:               # a helper thread is still blocked inside a collective: no orderly teardown is possible
+        sys.stdout.flush()
+        os._exit(0)
+
+
+def secondary_objects(a, out, ctx, stream, world, use_dist, device, systems, witnesses, sample, kernel_us):
+    """Everything of the line beside the headline, rank 0 only, each object under guard().  One GPU: all of it.  Several
+    ranks: the CPU baseline (short), the transform and the per-rank fractions -- the other ranks wait at the closing barrier."""
+    from concurrent.futures import ThreadPoolExecutor
+    single = world == 1 and not use_dist
+    pool = ThreadPoolExecutor(2)
+    # host-only preparation of the two 2^20-gate circuits (numpy + acx_circuit_create, ~7 s each) runs on helper threads
+    # while the counter passes below keep this process waiting on its children
+    need_c3 = single and any(a.want(x) for x in ("qap_h", "load", "cols", "e2e"))
+    other = "bls12_381" if a.field == "bn254" else "bn254"
+    c3_f = pool.submit(lambda: C3System(a.field).prepare()) if need_c3 else None
+    c3o_f = pool.submit(lambda: C3System(other).prepare()) if single and a.want("field2") else None
+
+    live = guard("pmc_fetch", measure_traffic_live, a) if single and a.want("pmc") else None
+    if live is not None:
+        # HBM bytes of the headline kernel measured in THIS run: a rocprofv3 --pmc FETCH_SIZE pass of its own over the
+        # same batched launches in a child process (counters need the profiler around the process)
+        out["roofline"]["traffic"] = live[0]
+        out["roofline"]["traffic_measured_in_run"] = True
+        out["roofline"]["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE around a child run of this script's batched launches ({live[1]} launches "
+                                             "averaged); bytes = FETCH_SIZE (KiB) * 1024 * 2 (gfx950 reports half of wide coalesced reads)")
+        out["roofline"]["achieved_traffic"] = live[0] / kernel_us * 1e-3
+        out["roofline"]["frac_traffic"] = out["roofline"]["achieved_traffic"] / HBM_PEAK_GBS
+    live_valu = guard("pmc_valu", measure_counter_live, a, "SQ_INSTS_VALU") if live is not None else None      # second pass, its own run
+    ntt_valu = guard("pmc_ntt_valu", measure_ntt_valu_live, a) if live is not None and a.want("ntt") else None  # third: the transform's
+    try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))["acx::k_r1cs_sell"]
+        same = tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}
+        if live is not None:
+            if same:
+                out["roofline"]["traffic_committed_pass"] = tr["traffic_bytes_per_launch"]       # the earlier pass, for comparison
+            out["roofline"]["valu_issue"] = _valu_issue("acx::k_r1cs_sell", "valu_wave_insts_per_launch", kernel_us, {"field": a.field, "copies": a.copies, "logn": a.logn},
+                                                        live_valu[0] / live_valu[1] if live_valu else None)
+        elif same:
+            # NOT measured in this run: a constant from the committed rocprofv3 --pmc pass of the same command (PMC
+            # counters need the profiler around the process).  The live quantities of this line are the times.
+            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_measured_in_run"] = False
+            out["roofline"]["traffic_source"] = tr["source"]
+            out["roofline"]["traffic_measured_at_commit"] = tr.get("measured_at_commit")
+            # the same launch time against the bytes the kernel really moves (the algorithmic figure counts 36 bytes
+            # per C entry that the unit-C path never reads, and 36 instead of 40 per A / B entry)
+            out["roofline"]["achieved_traffic"] = tr["traffic_bytes_per_launch"] / kernel_us * 1e-3
+            out["roofline"]["frac_traffic"] = out["roofline"]["achieved_traffic"] / HBM_PEAK_GBS
+            out["roofline"]["valu_issue"] = _valu_issue("acx::k_r1cs_sell", "valu_wave_insts_per_launch", kernel_us, tr["workload"])
+    except (OSError, KeyError, ValueError):
+        pass
+
+    def put(key, where, fn, *args, **kw):
+        r = guard(where, fn, *args, **kw)
+        if r is not None:
+            out[key] = r
+        return r
+
+    if a.want("ntt"):
+        put("ntt", "ntt", bench_ntt, ctx, stream, a.field, prewarm=a.prewarm, live_valu=ntt_valu, batch=64 if single else 0)
+    if single and a.want("small"):
+        put("r1cs_small_coeff", "small", bench_small_coeff, ctx, stream, a.field, copies=a.copies, log_n=a.logn, prewarm=a.prewarm)
+    if single and a.want("ref"):
+        put("reference_bench", "ref", reference_bench, ctx, a.field)
+    c3 = None
+    if need_c3:
+        c3 = guard("c3_load", lambda: c3_f.result().load(ctx))
+    if c3 is not None:
+        if a.want("load"):
+            put("load", "load", bench_load, c3)
+        if a.want("qap_h"):
+            put("qap_h", "qap_h", bench_qap_h, ctx, stream, c3, prewarm=a.prewarm)
+        if a.want("cols"):
+            put("qap_columns", "cols", bench_qap_columns, ctx, stream, c3)
+    if single and a.want("e2e") and systems:
+        put("e2e", "e2e", bench_e2e, systems[0], sample[1], c3)
+    if c3 is not None:
+        c3.r.close()
+        c3 = None
+    if single and a.want("field2"):
+        put(other, "field2", bench_field_subrun, other, device, a.copies, a.logn, a.prewarm, c3o_f)
+    if a.want("cpu"):
+        put("cpu_baseline", "cpu", cpu_baseline, sample, a.field, 10.0 if single else 4.0, single)
+    pool.shutdown(wait=False)
 
 
 if __name__ == "__main__":

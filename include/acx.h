@@ -153,12 +153,34 @@ int acx_circuit_eval(const acx_circuit* c, const acx_fr* inputs, const uint8_t* 
 int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots,
                         acx_r1cs** out);
 /* The reference takes roots as one list PER GATE (`[[k]]`, src/QAP.hs:530-539) and panics when a gate's list has
- * the wrong length (src/QAP.hs:444-445,474).  A host that flattens the lists calls this first: counts[g] =
+ * the wrong length (src/QAP.hs:444-445,474).  A host that flattens the lists itself calls this first: counts[g] =
  * length of gate g's list, n_lists = number of lists; ACX_ERR_ROOT_COUNT unless n_lists == #gates and every
- * count equals the gate's row count.  Two deliberate deviations from the reference's corner cases:
- * duplicate roots are an error here (ACX_ERR_DUPLICATE_ROOT) where `Map.fromList` would silently keep the
- * last row, and surplus root lists are an error where `zipWith` + `addMissingZeroes` would append zero rows. */
+ * count equals the gate's row count.  This flat form is STRICT: duplicate roots are an error (ACX_ERR_DUPLICATE_ROOT) and so
+ * are surplus or missing lists.  A drop-in host uses acx_circuit_to_r1cs_lists with ACX_ROOTS_REFERENCE_SEMANTICS instead,
+ * which returns what the reference returns on such lists. */
 int acx_circuit_check_root_counts(const acx_circuit* c, const uint32_t* counts, uint64_t n_lists);
+/* `arithCircuitToGenQAP rootsPerGate circuit` (src/QAP.hs:530-539) taking the roots as the reference does -- one list PER
+ * GATE: roots = the lists concatenated, counts[g] = length of list g, n_lists = number of lists -- so that a host need not
+ * check or flatten anything itself.  flags = 0: the strict contract above (ACX_ERR_ROOT_COUNT unless there is one list per gate
+ * of the gate's row count, ACX_ERR_DUPLICATE_ROOT on a repeated root).  flags = ACX_ROOTS_REFERENCE_SEMANTICS: the
+ * reference's own result on degenerate lists, value for value --
+ *   - `zipWith` (src/QAP.hs:539): lists beyond the last gate make no rows; gates beyond the last list are dropped;
+ *   - `Map.fromList` per wire (src/QAP.hs:233-239): of two rows with the SAME root the later one wins on every wire it
+ *     mentions (the constant and the explicit zeros of src/QAP.hs:396-473 included), other wires keep the earlier value;
+ *   - `addMissingZeroes (concat rootsPerGate)` (src/QAP.hs:566-576): every root of every list owns a row, zero if no gate
+ *     wrote it.
+ * The system then has one row per DISTINCT root, in ascending order; a list whose length does not fit its gate stays the
+ * reference's panic (src/QAP.hs:444-445,474): ACX_ERR_ROOT_COUNT.  Regular lists (what `generateRoots` produces) take the same
+ * path as acx_circuit_to_r1cs; a degenerate system has no GPU evaluation plan (acx_r1cs_eval: ACX_ERR_UNSUPPORTED). */
+enum { ACX_ROOTS_REFERENCE_SEMANTICS = 1 };
+int acx_circuit_to_r1cs_lists(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, const uint32_t* counts, uint64_t n_lists,
+                              uint32_t flags, acx_r1cs** out);
+/* The same rows on the host (pure host code, no device).  Every output may be NULL: call once for *n_rows (the number of
+ * distinct roots) and *nnz, then again with rowptr[*n_rows + 1], col / val[*nnz] and sorted_roots[*n_rows] (the distinct roots
+ * ascending = the abscissae of the naive path, `createPolynomials` src/QAP.hs:486-508). */
+int acx_circuit_rows_lists(const acx_circuit* c, const acx_fr* roots, const uint32_t* counts, uint64_t n_lists, uint32_t flags,
+                           int matrix, uint64_t* n_rows, uint64_t* nnz, uint32_t* rowptr, uint32_t* col, acx_fr* val,
+                           acx_fr* sorted_roots);
 /* The same rows on the host (pure host code), e.g. for a multi-GPU host that shards rows before
  * acx_r1cs_load.  Call acx_circuit_nnz first to size the buffers: rowptr[n_rows+1], col/val[nnz]. */
 int acx_circuit_nnz(const acx_circuit* c, uint64_t nnz[3]);

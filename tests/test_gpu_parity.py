@@ -948,7 +948,7 @@ def test_bench_ranks_on_one_device(world):
     env = dict(os.environ, ACX_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(H.free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "20",
-           "--warmup", "3", "--copies", "4", "--no-cpu", "--no-ntt", "--dist-logn", "18"]
+           "--warmup", "3", "--copies", "4", "--no-ntt", "--dist-logn", "18"] + (["--no-cpu"] if world == 8 else [])
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -957,10 +957,82 @@ def test_bench_ranks_on_one_device(world):
     assert d["n_gpus"] == world and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["constraints_per_step_per_gpu"] == 4 << 16
     assert abs(d["value"] - world * (4 << 16) * 20 / (d["ms_per_step"] * 20 * 1e-3)) / d["value"] < 1e-6
-    assert "cpu_baseline" not in d and "roofline" in d
+    assert "roofline" in d and "errors" not in d
+    # an N > 1 line is complete too: every rank's launch time and roofline fraction, and (rank 0) the CPU baseline
+    assert len(d["roofline"]["per_rank_kernel_us"]) == world and len(d["roofline"]["per_rank_frac"]) == world
+    assert ("cpu_baseline" in d) == (world != 8)
+    if world != 8:
+        assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     # the multi-rank line also times the distributed transform and the distributed h(x) (here 2^18, odd digits 9+9)
     assert d["dist_ntt"]["parity_vs_oracle"] is True and d["dist_ntt"]["all_to_all_bytes_per_rank"] == (1 << 18) // world * 32 * (world - 1) // world
     assert d["dist_qap_h"]["accepts_valid_rejects_corrupt"] is True and d["dist_qap_h"]["us"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_survives_secondary_failures():
+    """A secondary measurement that fails becomes an entry of "errors" and the line is still printed with its headline value
+    (ACX_BENCH_FAIL injects the failure); a multi-rank run in which one rank never joins the distributed extras prints its
+    line when the deadline passes and exits 0 on every rank (ACX_BENCH_HANG_DIST)."""
+    _need_gpu()
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--copies", "4", "--only", "ntt,small", "--sustain", "0"]
+    out = subprocess.run(cmd, cwd=root, env=dict(os.environ, ACX_BENCH_FAIL="ntt"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value"] > 0 and "ntt" not in d and "r1cs_small_coeff" in d
+    assert [e["where"] for e in d["errors"]] == ["ntt"] and "injected" in d["errors"][0]["error"]
+    env = dict(os.environ, ACX_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", ACX_BENCH_HANG_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(H.free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "10",
+           "--warmup", "2", "--copies", "2", "--skip", "cpu,ntt", "--dist-logn", "16", "--dist-deadline", "8"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "dist_ntt" not in d
+    assert any(e["error"] == "timeout" for e in d["errors"])
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_objects():
+    """The one-GPU line carries the whole contract: the reference's own benchmarked operations on configs[0], the load path
+    and the per-wire polynomials of configs[2], the PCIe-inclusive host-buffer figures, the field swap of configs[4] -- each
+    parity-gated (counter passes and the CPU baseline are left to the driver's own run)."""
+    _need_gpu()
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--skip", "pmc,cpu,small", "--sustain", "0"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "errors" not in d, d.get("errors")
+    rb = d["reference_bench"]
+    assert rb["evalArithCircuit"]["parity_vs_oracle"] and rb["arithCircuitToGenQAP"]["parity_vs_oracle"]
+    assert rb["arithCircuitToQAPFFT"]["parity_vs_oracle"] and rb["arithCircuitToQAP"]["parity_vs_interpolation_conditions"]
+    assert d["load"]["export_matches_host_rows"] and d["load"]["circuit_create_s"] > 0 and d["load"]["to_r1cs_s"] > 0
+    assert d["qap_h"]["parity_vs_oracle"] and d["qap_columns"]["parity_vs_oracle"] and d["ntt"]["parity_vs_oracle"]
+    for k in ("verify_pageable", "verify_pinned", "verify_pageable_4_callers", "verify_pinned_4_callers", "verify_many_pageable", "verify_many_pinned"):
+        assert d["e2e"][k]["constraints_per_s"] > 0
+    b = d["bls12_381"]
+    assert b["r1cs_verify"]["parity_vs_oracle"] and b["ntt"]["parity_vs_oracle"] and b["qap_h"]["parity_vs_oracle"]
+
+
+@pytest.mark.gpu
+def test_bench_mgpu_launcher_line():
+    """`bench.py --launcher mgpu` (ONE process, acx_mgpu_*): the line carries roofline and cpu_baseline like the driver's,
+    with one shard over RCCL and with two shards on one GPU (peer-copy transport)."""
+    _need_gpu()
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, shards in ((["--gpus", "1"], 1), (["--mgpu-devices", "0,0", "--skip", "cpu"], 2)):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--launcher", "mgpu", "--steps", "10", "--copies", "4"] + extra
+        out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["value"] > 0 and d["parity_vs_oracle"] is True and "errors" not in d
+        assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_us"] > 0
+        assert ("cpu_baseline" in d) == (shards == 1)
+        assert d["mgpu_qap_h"]["accepts_valid_rejects_corrupt"] is True
 
 
 @pytest.mark.gpu

@@ -16,7 +16,7 @@ for rnd in range(a.rounds):
         for v in a.variants:
             name, _, path = v.partition("=")
             env = dict(os.environ, ACX_LIB=os.path.abspath(path))
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-pmc", "--steps", "20", "--sustain", "0", "--field", field], env=env, capture_output=True, text=True)
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--only", "ntt,qap_h", "--steps", "20", "--sustain", "0", "--field", field], env=env, capture_output=True, text=True)
             try:
                 line = json.loads(out.stdout.strip().splitlines()[-1])
                 rows.setdefault((field, name), []).append((line["ntt"]["us"], line["ntt"]["batch"]["us_per_transform"], line["qap_h"]["us"],
