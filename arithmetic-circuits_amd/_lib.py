@@ -63,6 +63,8 @@ SYMBOLS = {
     "acx_circuit_eval": (_I, [_P, _P, _P, _U64, _P, _P]),
     "acx_circuit_to_r1cs": (_I, [_P, _P, _P, _U64, C.POINTER(_P)]),
     "acx_circuit_check_root_counts": (_I, [_P, _P, _U64]),
+    "acx_circuit_to_r1cs_lists": (_I, [_P, _P, _P, _P, _U64, _U32, C.POINTER(_P)]),
+    "acx_circuit_rows_lists": (_I, [_P, _P, _P, _U64, _U32, _I, C.POINTER(_U64), C.POINTER(_U64), _P, _P, _P, _P]),
     "acx_circuit_nnz": (_I, [_P, C.POINTER(_U64 * 3)]),
     "acx_circuit_rows": (_I, [_P, _P, _U64, _I, _P, _P, _P]),
     "acx_r1cs_load": (_I, [_P, _U64, _U64, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), C.POINTER(_P)]),
@@ -140,7 +142,13 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
+        # ACX_LIB_HOST_ONLY=1 (with ACX_LIB): the library is the sanitizer build of the pure-host entry points
+        # (csrc/host_only.cpp, tests/test_host_sanitized.py) -- only the symbols it has are bound; everything else of the ABI
+        # is absent there and using it fails loudly (AttributeError), as it must
+        host_only = os.environ.get("ACX_LIB_HOST_ONLY") == "1" and "ACX_LIB" in os.environ
         for name, (res, args) in SYMBOLS.items():
+            if host_only and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

@@ -386,6 +386,43 @@ class Circuit:
             out.append((rowptr, col, val))
         return out
 
+    @staticmethod
+    def _lists(root_lists: Sequence[Sequence[int]]):
+        counts = np.ascontiguousarray([len(rs) for rs in root_lists] or [0], dtype=np.uint32)
+        flat = [int(r) for rs in root_lists for r in rs]
+        roots = ints_to_fr(flat) if flat else np.zeros((1, 4), dtype=np.uint64)
+        return roots, counts, len(root_lists)
+
+    def rows_lists(self, root_lists: Sequence[Sequence[int]], reference_semantics: bool = True):
+        """`arithCircuitToGenQAP rootsPerGate circuit` on the host with the roots as ONE LIST PER GATE (canonical ints):
+        ([(rowptr, col, val)] x 3, sorted distinct roots).  reference_semantics: duplicated roots merge rows the way
+        `Map.fromList` does, surplus lists append zero rows, missing lists drop gates (src/QAP.hs:233-239,530-539,566-576)."""
+        roots, counts, n_lists = self._lists(root_lists)
+        flags = 1 if reference_semantics else 0
+        out, sorted_roots = [], None
+        for k in range(3):
+            n, nnz = C.c_uint64(), C.c_uint64()
+            check(self.lib.acx_circuit_rows_lists(self._h, _ptr(roots), _ptr(counts), n_lists, flags, k, C.byref(n), C.byref(nnz),
+                                                  None, None, None, None))
+            rowptr = np.zeros(n.value + 1, dtype=np.uint32)
+            col = np.zeros(nnz.value, dtype=np.uint32)
+            val = np.zeros((nnz.value, 4), dtype=np.uint64)
+            sr = np.zeros((n.value, 4), dtype=np.uint64)
+            check(self.lib.acx_circuit_rows_lists(self._h, _ptr(roots), _ptr(counts), n_lists, flags, k, None, None,
+                                                  _ptr(rowptr), _ptr(col), _ptr(val), _ptr(sr)))
+            out.append((rowptr, col, val))
+            sorted_roots = fr_to_ints(sr)
+        return out, sorted_roots
+
+    def to_r1cs_lists(self, ctx: Context, root_lists: Sequence[Sequence[int]], reference_semantics: bool = True) -> R1CS:
+        """acx_circuit_to_r1cs_lists: the device system of `arithCircuitToGenQAP rootsPerGate circuit`, roots as per-gate lists."""
+        if ctx.field != self.field:
+            raise ValueError("context and circuit are over different fields")
+        roots, counts, n_lists = self._lists(root_lists)
+        h = C.c_void_p()
+        check(self.lib.acx_circuit_to_r1cs_lists(ctx._h, self._h, _ptr(roots), _ptr(counts), n_lists, 1 if reference_semantics else 0, C.byref(h)))
+        return R1CS(ctx, h)
+
     def to_r1cs(self, ctx: Context, roots: Optional[np.ndarray] = None) -> R1CS:
         if ctx.field != self.field:
             raise ValueError("context and circuit are over different fields")

@@ -124,22 +124,16 @@ class NaiveQAP(QAP):
         return fr_to_ints(coeffs[0, : int(lens[0])])
 
 
-def _roots_array(p: int, roots: Optional[Sequence[Sequence[int]]], circuit) -> Optional[np.ndarray]:
-    if roots is None:
-        return None
-    # the reference panics on a wrong per-gate count (src/QAP.hs:445,474); the C ABI validates the counts
-    # (acx_circuit_check_root_counts) and surfaces the same condition as ACX_ERR_ROOT_COUNT
-    circuit.check_root_counts([len(rs) for rs in roots])
-    flat: List[int] = [r % p for rs in roots for r in rs]
-    return ints_to_fr(flat) if flat else np.zeros((0, 4), dtype=np.uint64)
-
-
 def arithCircuitToGenQAP(ctx: Context, roots: Optional[Sequence[Sequence[int]]], circuit: ArithCircuit) -> GenQAP:
-    """src/QAP.hs:530-539.  `roots` = one list per gate (None = fresh numbering)."""
-    if roots is not None and len(roots) < len(circuit.gates):
-        circuit = ArithCircuit(circuit.gates[: len(roots)])   # zipWith truncates to the shorter list
+    """src/QAP.hs:530-539.  `roots` = one list per gate (None = fresh numbering).  The lists cross the C ABI as they are
+    (acx_circuit_to_r1cs_lists with ACX_ROOTS_REFERENCE_SEMANTICS): a list of the wrong length for its gate is the reference's
+    panic (src/QAP.hs:445,474) = AcxError ROOT_COUNT; repeated roots, surplus and missing lists give what the reference gives
+    (`Map.fromList` merging, `addMissingZeroes`, `zipWith` truncation)."""
     c = circuit.marshal(ctx.field)
-    r = c.to_r1cs(ctx, _roots_array(ctx.p, roots, c))
+    if roots is None:
+        r = c.to_r1cs(ctx)
+    else:
+        r = c.to_r1cs_lists(ctx, [[x % ctx.p for x in rs] for rs in roots])
     return GenQAP(ctx, r, c.n_inputs, c.n_intermediates, c.n_outputs)
 
 
@@ -156,12 +150,12 @@ def createPolynomials(gen: GenQAP, roots: Sequence[Sequence[int]]) -> NaiveQAP:
     """src/QAP.hs:486-508.  The GenQAP here does not carry the root values (rows are stored in
     ascending-root order), so they are passed again."""
     p = gen.ctx.p
-    return NaiveQAP(gen, sorted(r % p for rs in roots for r in rs))
+    return NaiveQAP(gen, sorted({r % p for rs in roots for r in rs}))      # the Map's keys: distinct, ascending
 
 
 def arithCircuitToQAP(ctx: Context, roots: Sequence[Sequence[int]], circuit: ArithCircuit) -> NaiveQAP:
     """src/QAP.hs:542-549."""
-    return createPolynomials(arithCircuitToGenQAP(ctx, roots, circuit), roots[: len(circuit.gates)])
+    return createPolynomials(arithCircuitToGenQAP(ctx, roots, circuit), roots)     # `concat rootsPerGate`: surplus lists included
 
 
 def gateToQAP(ctx: Context, roots: Sequence[int], gate: Gate) -> QAP:

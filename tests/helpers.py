@@ -61,6 +61,26 @@ def arb_arith_circuit(rnd: random.Random, p: int, num_inps: int, size: int, dist
     return gates
 
 
+def degenerate_root_lists(rnd: random.Random, gates, mode: str, pool: int = 0) -> List[List[int]]:
+    """Per-gate root lists (src/QAP.hs:530-539 takes `[[k]]`) that the reference accepts without being what `generateRoots`
+    makes: `dup` -- roots drawn from a pool smaller than the row count, so rows of different gates (and of one Equal / Split
+    gate) share roots; `surplus` -- extra lists behind the last gate, some repeating earlier roots; `missing` -- fewer lists
+    than gates; `mixed` -- repeated roots with either of the two.  Every list keeps the length its gate demands (the reference panics otherwise)."""
+    lists = R.fresh_roots(gates, 1)
+    total = sum(len(rs) for rs in lists)
+    if mode in ("dup", "mixed"):
+        pool = pool or max(2, total // 2)
+        lists = [[1 + rnd.randrange(pool) for _ in rs] for rs in lists]
+    if mode == "mixed":                         # with lists missing, lists appended behind would pair with gates
+        mode = rnd.choice(["missing", "surplus"])
+    if mode == "missing" and len(lists) > 1:
+        lists = lists[: rnd.randrange(1, len(lists))]
+    if mode == "surplus":
+        for _ in range(rnd.randrange(1, 4)):
+            lists.append([rnd.randrange(1, total + 20) for _ in range(rnd.randrange(0, 4))])
+    return lists
+
+
 def arb_input_vector(rnd: random.Random, p: int, num_vars: int) -> Dict[int, int]:
     return {i: rnd.randrange(p) for i in range(num_vars)}
 

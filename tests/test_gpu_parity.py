@@ -674,6 +674,47 @@ def test_prop_arithCircuitToQAP_slow_gpu(request, acx, field, seed):
         assert acx.verificationWitness(qap, _acx_qapset(acx, ra)) is None and R.verification_witness(want, ra, p) is None
 
 
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("mode", ["dup", "surplus", "missing", "mixed"])
+def test_degenerate_root_lists_on_the_device(request, acx, field, mode):
+    """Bar (1) on the inputs the strict contract used to refuse: root lists with repeated roots, surplus lists and missing
+    lists (/root/reference/src/QAP.hs:233-239,530-539,566-576) through acx_circuit_to_r1cs_lists with
+    ACX_ROOTS_REFERENCE_SEMANTICS -- target, every per-wire polynomial, verifyAssignment, verificationWitness and its
+    zero-knowledge variant equal the literal oracle's, on the FFT path and on the naive path."""
+    ctx = _ctx(request, field)
+    fld = FIELDS[field]
+    p = fld.p
+    seen_true = seen_false = 0
+    for seed in range(4):
+        rnd = random.Random(9300 + 31 * seed + len(mode))
+        nv = rnd.randrange(1, 4)
+        gates = H.arb_arith_circuit(rnd, p, nv, 4 + 2 * seed, dist=(50, 25, 10), split_bits=3)
+        lists = H.degenerate_root_lists(rnd, gates, mode)
+        program = H.to_acx_circuit(acx, gates)
+        dims = H.circuit_dims(gates)
+        for qap, want in ((acx.arithCircuitToQAPFFT(ctx, lists, program), R.arith_circuit_to_qap_fft(fld.root_of_unity, lists, gates, p)),
+                          (acx.arithCircuitToQAP(ctx, lists, program), R.arith_circuit_to_qap(lists, gates, p))):
+            assert qap.qapTarget == want.target
+            assert qap.gen.r1cs.n == len({r % p for rs in lists for r in rs})
+            for getter, qs in ((qap.qapInputsLeft, want.left), (qap.qapInputsRight, want.right), (qap.qapOutputs, want.out)):
+                assert getter(flat=0) == qs.constant
+                for kind, part in enumerate((qs.inputs, qs.intermediates, qs.outputs)):
+                    for idx, poly in part.items():
+                        assert getter(flat=H.flat_index(dims, R.Wire(kind, idx))) == poly
+            for t in range(3):
+                ra = R.generate_assignment(gates, H.arb_input_vector(rnd, p, nv), p)
+                if t == 2:          # the all-zero assignment satisfies every merged row whose constants vanish: both outcomes get exercised
+                    ra = R.QapSet(0, {}, {}, {})
+                a = _acx_qapset(acx, ra)
+                ok = R.verify_assignment(want, ra, p)
+                seen_true, seen_false = seen_true + ok, seen_false + (not ok)
+                assert acx.verifyAssignment(qap, a) == ok
+                assert acx.verificationWitness(qap, a) == R.verification_witness(want, ra, p)
+                d = [rnd.randrange(p) for _ in range(3)]
+                assert acx.verificationWitnessZk(d[0], d[1], d[2], qap, a) == R.verification_witness_zk(d[0], d[1], d[2], want, ra, p)
+    assert seen_false > 0 and (seen_true > 0 or mode == "dup")
+
+
 def test_naive_errors(request, acx):
     ctx = _ctx(request, "bn254")
     gen = acx.arithCircuitToGenQAP(ctx, [[7], [8], [9]], _kat_program(acx))

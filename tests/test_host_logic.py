@@ -95,6 +95,42 @@ def test_root_order_and_errors(acx):
     assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
 
 
+@pytest.mark.parametrize("fname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("mode", ["dup", "surplus", "missing", "mixed"])
+@pytest.mark.parametrize("seed", range(4))
+def test_degenerate_root_lists_follow_the_reference(acx, fname, mode, seed):
+    """`arithCircuitToGenQAP` on root lists with repeated roots, surplus lists and missing lists: the rows
+    acx_circuit_rows_lists(ACX_ROOTS_REFERENCE_SEMANTICS) returns equal the literal restatement's GenQAP entry for entry
+    (`Map.fromList` overwrite per wire incl. explicit zeros, `zipWith` truncation, `addMissingZeroes`:
+    /root/reference/src/QAP.hs:233-239,530-539,566-576), the strict form refuses the same lists, and a list of the wrong
+    length stays the reference's panic."""
+    p = (R.BN254 if fname == "bn254" else R.BLS12_381).p
+    rnd = random.Random(4100 + 17 * seed + len(mode))
+    gates = H.arb_arith_circuit(rnd, p, 3, 5 + 2 * seed, dist=(50, 30, 15), split_bits=3)
+    lists = H.degenerate_root_lists(rnd, gates, mode)
+    circ = H.to_acx_circuit(acx, gates).marshal(fname)
+    dims = H.circuit_dims(gates)
+    gen = R.arith_circuit_to_gen_qap(lists, gates, p)
+    n, m, want = H.gen_qap_to_csr(gen, dims, p)
+    got, roots = circ.rows_lists(lists)
+    assert roots == sorted(gen.target) and len(roots) == n == len({r for rs in lists for r in rs})
+    for k in range(3):
+        assert H.csr_equal(got[k], want[k]), f"matrix {k}"
+    regular = len(lists) == len(gates) and len({r for rs in lists for r in rs}) == sum(len(rs) for rs in lists)
+    if not regular:
+        with pytest.raises(acx.AcxError) as e:
+            circ.rows_lists(lists, reference_semantics=False)
+        assert e.value.status in (acx._lib.STATUS["ROOT_COUNT"], acx._lib.STATUS["DUPLICATE_ROOT"])
+    # a list of the wrong length for its gate: `panic "gateToGenQAP: wrong number of roots supplied"` (src/QAP.hs:444-445,474)
+    bad = [list(rs) for rs in lists]
+    bad[0] = bad[0] + [7]
+    with pytest.raises(R.ReferencePanic):
+        R.arith_circuit_to_gen_qap(bad, gates, p)
+    with pytest.raises(acx.AcxError) as e:
+        circ.rows_lists(bad)
+    assert e.value.status == acx._lib.STATUS["ROOT_COUNT"]
+
+
 def test_eval_undefined_wire_is_an_error_code(acx):
     """src/Circuit/Arithmetic.hs:128,137 panic -> ACX_ERR_UNDEFINED_WIRE."""
     for gate in (acx.Equal(acx.IntermediateWire(5), acx.IntermediateWire(0), acx.OutputWire(0)),
