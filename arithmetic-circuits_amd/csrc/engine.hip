@@ -1361,6 +1361,9 @@ int qap_columns_core(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t cnt,
 
 }  // namespace
 
+int qap_columns_host(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out, uint64_t* out_len,
+                     uint64_t max_batch_bytes);
+
 // ==================================================================================== C ABI
 extern "C" {
 
@@ -1965,6 +1968,15 @@ int acx_qap_columns_dev(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t w
 
 int acx_qap_columns(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out,
                     uint64_t* out_len) {
+    return qap_columns_host(r, matrix, wire_begin, wire_count, out, out_len, 1ull << 30);
+}
+
+}  // extern "C"
+
+// acx_qap_columns with the size of a device-side batch of coefficients bounded by the caller (the N-GPU handle runs one of
+// these per shard and bounds the sum)
+int qap_columns_host(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out, uint64_t* out_len,
+                     uint64_t max_batch_bytes) {
     if (!r || matrix < 0 || matrix > 2 || !out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
     if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
     if (wire_count == 0) return ACX_OK;
@@ -1976,7 +1988,7 @@ int acx_qap_columns(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_
     // Wire batches of bounded size (<= 1 GiB of coefficients each), double buffered: while the host thread sits in
     // the blocking device-to-host copy of batch k (on the lane's copy stream), batch k+1 is already scattered and
     // transformed on the lane's compute stream.
-    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(1, (1ull << 30) / (N * 32)), wire_count);
+    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(1, max_batch_bytes / (N * 32)), wire_count);
     const size_t cb = align256(chunk * N * 32), lb = align256(chunk * 8);
     uint8_t* base = nullptr;
     ACX_TRY(lane_reserve(c, 2 * (cb + lb), &base));
@@ -2003,6 +2015,69 @@ int acx_qap_columns(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_
     }
     return fetch(n_chunks - 1);
 }
+
+// Scratch of the host-buffer entry points (lane arenas, transform ping-pong buffers) back to the device: what a caller that
+// keeps many contexts on one device (the N-GPU handle with a repeated ordinal) does after a call with large outputs.
+void ctx_trim_scratch(acx_ctx* c) {
+    CtxLock lock(c->mu);
+    (void)hipSetDevice(c->device);
+    for (auto& ln : c->lanes) {
+        std::lock_guard<std::mutex> g(ln.mu);
+        if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+        if (ln.copy_stream) (void)hipStreamSynchronize(ln.copy_stream);
+        if (ln.arena) { (void)hipFree(ln.arena); ln.arena = nullptr; ln.arena_bytes = 0; }
+        if (ln.ntt_scratch) { (void)hipFree(ln.ntt_scratch); ln.ntt_scratch = nullptr; ln.ntt_scratch_bytes = 0; }
+    }
+}
+
+// A constraint system of which ONE DEVICE holds only the column view of some wires (the N-GPU handle's share of
+// `createPolynomialsFFT`, src/QAP.hs:512-525: a wire's interpolation needs every row of ITS column and nothing else): an
+// acx_r1cs with no row form at all -- m = the number of local wires, T[k] = the CSC of matrix k over them (local column
+// numbers, canonical values in, dev format on the device).  Serves acx_qap_columns / qap_columns_host only.
+struct HostCsc {
+    std::vector<uint32_t> colptr, rowidx, colid;
+    std::vector<acx_fr> val;
+};
+int r1cs_column_slice_from_host(acx_ctx* ctx, uint64_t n, uint32_t log_n, uint64_t m_local, const HostCsc csc[3], acx_r1cs** out) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<acx_r1cs> r(new acx_r1cs());
+    r->ctx = ctx; r->n = n; r->m = m_local; r->log_n = log_n;
+    int rc = ACX_OK;
+    {
+        LaneGuard lane(ctx);
+        auto build = [&]() -> int {
+            for (int k = 0; k < 3; ++k) {
+                DevMatrix& T = r->T[k];
+                const uint64_t nnz = csc[k].rowidx.size();
+                T.nnz = nnz;
+                HIP_TRY(hipMalloc((void**)&T.ptr, (m_local + 1) * 4));
+                HIP_TRY(hipMalloc((void**)&T.idx, std::max<uint64_t>(nnz, 1) * 4));
+                HIP_TRY(hipMalloc((void**)&T.colid, std::max<uint64_t>(nnz, 1) * 4));
+                HIP_TRY(hipMalloc((void**)&T.val, std::max<uint64_t>(nnz, 1) * 32));
+                HIP_TRY(hipMemcpyAsync(T.ptr, csc[k].colptr.data(), (m_local + 1) * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+                if (nnz) {
+                    HIP_TRY(hipMemcpyAsync(T.idx, csc[k].rowidx.data(), nnz * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+                    HIP_TRY(hipMemcpyAsync(T.colid, csc[k].colid.data(), nnz * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+                    ACX_TRY(upload_elements(ctx, csc[k].val.data(), nnz, T.val));      // canonical -> dev, canonicity checked, synchronises
+                }
+                T.h_ptr = csc[k].colptr;
+            }
+            HIP_TRY(hipStreamSynchronize(cur_stream(ctx)));
+            return ACX_OK;
+        };
+        rc = build();
+    }
+    if (rc != ACX_OK) {
+        (void)hipDeviceSynchronize();
+        free_r1cs_device(r.get());
+        return rc;
+    }
+    r->has_csc = true;
+    *out = r.release();
+    return ACX_OK;
+}
+
+extern "C" {
 
 // ---------------------------------------------------------------------------------- NTT
 int acx_ntt(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift, const acx_fr* in,

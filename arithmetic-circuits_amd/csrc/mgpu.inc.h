@@ -36,6 +36,8 @@
 #include <link.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <functional>
 #include <thread>
 
 namespace {
@@ -49,6 +51,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllToAll)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -89,6 +92,7 @@ static const RcclApi* rccl_api(std::string& why) {
             api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
             api.AllToAll = reinterpret_cast<decltype(api.AllToAll)>(sym("ncclAllToAll"));
             api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+            api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
             api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
         }
     }
@@ -102,8 +106,128 @@ static const RcclApi* rccl_api(std::string& why) {
         if (r_ != ncclSuccess) return fail(ACX_ERR_HIP, std::string(#expr) + ": " + (mg)->api->GetErrorString(r_)); \
     } while (0)
 
+// ---- one persistent issuing thread per shard ------------------------------------------------------------
+// A call on the handle is W independent streams of API calls (launches, event records and waits, copies: ~50 per shard per
+// h(x)).  Issued from one thread they are serial -- W x 50 calls of 2-5 us each against a few milliseconds of device time --
+// so every shard has its own host thread for the life of the handle (no thread creation per call either: that alone was
+// 20-50 us per shard).  run(fn) hands fn(shard) to every worker and returns when all are done; the first failure (and the
+// failing thread's message) is carried back.  With RCCL each thread drives its own communicator (the documented
+// multi-threaded single-process pattern) and nothing crosses threads on the host.  With the peer-copy transport a shard waits
+// on events its PEERS record, and a wait on an event not yet recorded is a no-op: barrier() orders those host-side
+// (a worker that has failed releases the barrier for everybody: no deadlock on the error path).
+struct MgPool {
+    uint32_t W = 0;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<int(uint32_t)>* job = nullptr;
+    uint64_t gen = 0;
+    uint32_t pending = 0;
+    bool stop = false;
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+    std::mutex bmu;
+    std::condition_variable bcv;
+    uint32_t bcount = 0;
+    uint64_t bgen = 0;
+    bool aborted = false;
+
+    void start(uint32_t w, const std::vector<int>& devices) {
+        W = w;
+        rc.assign(W, ACX_OK);
+        msg.assign(W, std::string());
+        for (uint32_t s = 0; s < W; ++s) th.emplace_back([this, s, dev = devices[s]] { loop(s, dev); });
+    }
+    void loop(uint32_t s, int device) {
+        (void)hipSetDevice(device);
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<int(uint32_t)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv_go.wait(l, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                fn = job;
+            }
+            int r = ACX_OK;
+            try {
+                (void)hipSetDevice(device);
+                r = (*fn)(s);
+            } catch (const std::bad_alloc&) {
+                r = fail(ACX_ERR_OOM, "host allocation failed");
+            } catch (...) {
+                r = fail(ACX_ERR_INVALID_ARG, "unexpected exception");
+            }
+            if (r != ACX_OK) {
+                std::lock_guard<std::mutex> b(bmu);
+                aborted = true;
+                bcv.notify_all();
+            }
+            std::lock_guard<std::mutex> l(mu);
+            rc[s] = r;
+            if (r != ACX_OK) msg[s] = g_last_error;
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    int run(const std::function<int(uint32_t)>& fn) {
+        {
+            std::lock_guard<std::mutex> b(bmu);
+            aborted = false;
+            bcount = 0;
+        }
+        std::unique_lock<std::mutex> l(mu);
+        job = &fn;
+        pending = W;
+        ++gen;
+        cv_go.notify_all();
+        cv_done.wait(l, [&] { return pending == 0; });
+        for (uint32_t s = 0; s < W; ++s)
+            if (rc[s] != ACX_OK) return fail(rc[s], msg[s]);
+        return ACX_OK;
+    }
+    // every worker of the current job; false: another worker failed, give up
+    bool barrier() {
+        std::unique_lock<std::mutex> l(bmu);
+        if (aborted) return false;
+        const uint64_t my = bgen;
+        if (++bcount == W) {
+            bcount = 0;
+            ++bgen;
+            bcv.notify_all();
+            return true;
+        }
+        bcv.wait(l, [&] { return aborted || bgen != my; });
+        return !aborted;
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto& t : th) if (t.joinable()) t.join();
+        th.clear();
+    }
+};
+
+// The receiving side of the peer-copy exchange for the sources that live on the receiver's OWN device (a device list with a
+// repeated ordinal: several shards on one GPU): block t of recv = block `me` of shard t's send buffer, every t in one launch
+// instead of one device-to-device copy per source (W x W copies per exchange made the one-GPU configuration host bound).
+struct MgPull {
+    const uint4* src[64];                           // send + me * chunk of every same-device source; null: not on this device
+};
+__global__ __launch_bounds__(kBlock) void k_pull_chunks(MgPull P, uint4* __restrict__ recv, u32 W, u64 chunk_quads) {
+    const u32 t = blockIdx.y;
+    if (t >= W || P.src[t] == nullptr) return;
+    const uint4* from = P.src[t];
+    uint4* to = recv + (u64)t * chunk_quads;
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < chunk_quads; i += (u64)gridDim.x * kBlock) to[i] = gload(from + i);
+}
+
 constexpr int kMgSlots = 3;          // transforms in flight (the three vectors of h(x))
 constexpr uint32_t kMgRing = 16;     // result slots of acx_mgpu_r1cs_verify_enqueue
+constexpr uint64_t kMgColBlock = 64; // wires per block of the block-cyclic WIRE ownership of acx_mgpu_qap_columns
 
 struct MgSlot {                      // one exchange buffer pair of one shard
     uint4 *send = nullptr, *recv = nullptr;
@@ -124,6 +248,9 @@ struct MgShard {
     uint64_t slot_elems = 0;
     uint4* io = nullptr;                            // staging of the natural-order host transfers (acx_mgpu_ntt, h fetch)
     uint64_t io_elems = 0;
+    hipEvent_t w_ready = nullptr;                   // shard 0: the converted witness is complete (peers pull it)
+    hipEvent_t w_read = nullptr;                    // other shards: their copy out of shard 0's buffer is done
+    bool w_read_valid = false;
 };
 
 }  // namespace
@@ -136,6 +263,11 @@ struct acx_mgpu {
     std::vector<MgShard> sh;
     uint32_t min_log_n = 14;                        // smaller systems stay on shard 0 (acx_mgpu_set_shard_threshold)
     std::mutex mu;                                  // one acx_mgpu_* call at a time: collectives are ordered
+    std::unique_ptr<MgPool> pool;                   // W > 1: one issuing thread per shard
+    int witness_mode = 0;                           // 0 broadcast (one H2D + device-side replication), 1 W host copies, 2 the same from registered memory
+    // wall clock of the last verify / h(x) call on this handle: entry -> everything enqueued (the HOST's share: API calls
+    // of the issuing threads) and entry -> results on the host.  acx_mgpu_debug_times (tools/mgpu_host.py).
+    double last_issue_s = 0, last_total_s = 0;
 };
 
 struct acx_mgpu_r1cs {
@@ -148,7 +280,8 @@ struct acx_mgpu_r1cs {
         acx_r1cs* slab = nullptr;                   // rows [row0, row0 + slab->n): what verifyAssignment runs on
         uint64_t row0 = 0;
         acx_r1cs* cyc = nullptr;                    // this shard's N/W block-cyclic rows in ascending order: what h(x) runs on (null: verify only)
-        acx_r1cs* full = nullptr;                   // the WHOLE system, for this shard's wires of acx_mgpu_qap_columns (built on its first call)
+        acx_r1cs* full = nullptr;                   // the WHOLE system (shard 0 only, on demand): acx_mgpu_qap_h of a size the four-step form does not cover
+        acx_r1cs* cols = nullptr;                   // the column view of THIS shard's wires (block-cyclic, kMgColBlock wires per block): acx_mgpu_qap_columns
         uint4* d_w = nullptr;                       // the replicated witness, m dev elements
         uint4* vec = nullptr;                       // h(x) pipeline: dots 3L | coef 3L | pw L | h L (allocated on first use)
         uint4* hscale = nullptr;                    // {1/z, -1/z} for the GLOBAL N as dev elements: ride on the stored dots of h(x) (qap_h_dev_locked)
@@ -164,6 +297,18 @@ struct acx_mgpu_r1cs {
 };
 
 namespace {
+
+struct MgClock {                                    // issue / total wall clock of one call, written to the handle on exit
+    acx_mgpu* mg;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double issue = -1;
+    explicit MgClock(acx_mgpu* m) : mg(m) {}
+    void issued() { issue = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    ~MgClock() {
+        mg->last_total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        mg->last_issue_s = issue < 0 ? mg->last_total_s : issue;
+    }
+};
 
 struct DevGuard {                                   // the calling thread's device is restored on exit
     int prev = 0;
@@ -215,7 +360,36 @@ int mg_ensure_io(acx_mgpu* mg, uint64_t L) {
     return ACX_OK;
 }
 
+// run fn(shard) for every shard, each on its shard's own persistent host thread (MgPool); the first failure and its message
+// are carried back to the calling thread.  One shard: on the calling thread.
+template <class Fn>
+int mg_per_shard_threads(acx_mgpu* mg, Fn&& fn) {
+    if (mg->W == 1 || !mg->pool) {
+        for (uint32_t s = 0; s < mg->W; ++s) {
+            int rc;
+            try {
+                rc = fn(s);
+            } catch (const std::bad_alloc&) {
+                rc = fail(ACX_ERR_OOM, "host allocation failed");
+            } catch (...) {
+                rc = fail(ACX_ERR_INVALID_ARG, "unexpected exception");
+            }
+            if (rc != ACX_OK) return rc;
+        }
+        return ACX_OK;
+    }
+    const std::function<int(uint32_t)> f = std::forward<Fn>(fn);
+    return mg->pool->run(f);
+}
+inline bool mg_barrier(acx_mgpu* mg) { return mg->W == 1 || !mg->pool || mg->pool->barrier(); }
+#define MG_BARRIER(mg)                                                                                       \
+    do {                                                                                                     \
+        if (!mg_barrier(mg)) return fail(ACX_ERR_HIP, "another shard's issuing thread failed");               \
+    } while (0)
+
 // ---- one distributed transform = begin (local step 0 + the START of the exchange) and finish (wait + local step 1) ----
+// Every method is the part of ONE shard, called by that shard's issuing thread (mg_per_shard_threads): the W threads run the
+// same sequence, so their barriers (peer-copy transport only) pair up.
 struct MgNtt {
     acx_mgpu* mg;
     uint32_t log_n, log_r;
@@ -225,170 +399,156 @@ struct MgNtt {
         chunk = L / m->W;
     }
 
-    int exchange(int k) {
+    int exchange(uint32_t s, int k) {
         const uint32_t W = mg->W;
-        if (mg->rccl) {
-            for (auto& s : mg->sh) {
-                HIP_TRY(hipSetDevice(s.device));
-                MgSlot& sl = s.slot[k];
-                HIP_TRY(hipStreamWaitEvent(s.xstream, sl.sent, 0));
-                if (sl.used_valid) HIP_TRY(hipStreamWaitEvent(s.xstream, sl.used, 0));       // previous reader of recv
-            }
-            NCCL_TRY(mg, mg->api->GroupStart());
-            for (auto& s : mg->sh) {
-                MgSlot& sl = s.slot[k];
-                const ncclResult_t r = mg->api->AllToAll(sl.send, sl.recv, chunk * 4, ncclUint64, s.comm, s.xstream);
-                if (r != ncclSuccess) { (void)mg->api->GroupEnd(); return fail(ACX_ERR_HIP, std::string("ncclAllToAll: ") + mg->api->GetErrorString(r)); }
-            }
-            NCCL_TRY(mg, mg->api->GroupEnd());
-            for (auto& s : mg->sh) {
-                HIP_TRY(hipSetDevice(s.device));
-                HIP_TRY(hipEventRecord(s.slot[k].got, s.xstream));
-                s.slot[k].got_valid = true;
-            }
+        MgShard& S = mg->sh[s];
+        MgSlot& sl = S.slot[k];
+        if (mg->rccl) {                                             // this shard's rank of THE all-to-all, on its own communicator
+            HIP_TRY(hipStreamWaitEvent(S.xstream, sl.sent, 0));
+            if (sl.used_valid) HIP_TRY(hipStreamWaitEvent(S.xstream, sl.used, 0));            // previous reader of recv
+            NCCL_TRY(mg, mg->api->AllToAll(sl.send, sl.recv, chunk * 4, ncclUint64, S.comm, S.xstream));
+            HIP_TRY(hipEventRecord(sl.got, S.xstream));
+            sl.got_valid = true;
             return ACX_OK;
         }
-        // peer copies: shard t PULLS block t of every shard's send buffer
+        // peer copies: this shard PULLS its block of every shard's send buffer.  The waits below are on events the peers'
+        // threads record: all of them must have been recorded first (a wait on an unrecorded event is a no-op).
+        MG_BARRIER(mg);
+        if (sl.used_valid) HIP_TRY(hipStreamWaitEvent(S.xstream, sl.used, 0));
+        MgPull pull{};
+        bool local = false;
         for (uint32_t t = 0; t < W; ++t) {
-            MgShard& dst = mg->sh[t];
-            HIP_TRY(hipSetDevice(dst.device));
-            MgSlot& dl = dst.slot[k];
-            if (dl.used_valid) HIP_TRY(hipStreamWaitEvent(dst.xstream, dl.used, 0));
-            for (uint32_t s = 0; s < W; ++s) {
-                MgShard& src = mg->sh[s];
-                HIP_TRY(hipStreamWaitEvent(dst.xstream, src.slot[k].sent, 0));
-                uint4* to = dl.recv + 2 * (uint64_t)s * chunk;
-                const uint4* from = src.slot[k].send + 2 * (uint64_t)t * chunk;
-                if (src.device == dst.device) HIP_TRY(hipMemcpyAsync(to, from, chunk * 32, hipMemcpyDeviceToDevice, dst.xstream));
-                else HIP_TRY(hipMemcpyPeerAsync(to, dst.device, from, src.device, chunk * 32, dst.xstream));
-            }
-            HIP_TRY(hipEventRecord(dl.got, dst.xstream));
-            dl.got_valid = true;
+            MgShard& src = mg->sh[t];
+            HIP_TRY(hipStreamWaitEvent(S.xstream, src.slot[k].sent, 0));
+            const uint4* from = src.slot[k].send + 2 * (uint64_t)s * chunk;
+            if (src.device == S.device) { pull.src[t] = from; local = true; }
+            else HIP_TRY(hipMemcpyPeerAsync(sl.recv + 2 * (uint64_t)t * chunk, S.device, from, src.device, chunk * 32, S.xstream));
         }
+        if (local) {
+            const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((2 * chunk + kBlock - 1) / kBlock, 4ull * S.ctx->n_cu / W + 1));
+            hipLaunchKernelGGL(k_pull_chunks, dim3(gx, W), dim3(kBlock), 0, S.xstream, pull, sl.recv, W, (u64)(2 * chunk));
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(sl.got, S.xstream));
+        sl.got_valid = true;
+        MG_BARRIER(mg);                                             // every `got` of this exchange is recorded: the next begin on slot k may wait on them
         return ACX_OK;
     }
 
-    // in[s]: L dev elements per shard (COLS for a forward, ROWS for an inverse transform)
+    // in: L dev elements of shard s (COLS for a forward, ROWS for an inverse transform)
     // rows_transposed: the input of an inverse transform is in ascending row order [k2][kl] (the residual kernel's dots)
-    // mul: the transform of the pointwise product in[s][i] * mul[s][i] (same layout)
-    int begin(int k, uint4* const* in, int inverse, const H256* shift, bool rows_transposed = false, uint4* const* mul = nullptr) {
+    // mul: the transform of the pointwise product in[i] * mul[i] (same layout)
+    int begin(uint32_t s, int k, const uint4* in, int inverse, const H256* shift, bool rows_transposed = false, const uint4* mul = nullptr) {
         const uint32_t W = mg->W;
-        for (uint32_t s = 0; s < W; ++s) {
-            MgShard& S = mg->sh[s];
-            HIP_TRY(hipSetDevice(S.device));
+        MgShard& S = mg->sh[s];
+        {
             CtxLock lock(S.ctx->mu);
             if (!mg->rccl)                                          // peers still pulling the previous contents of send
                 for (uint32_t t = 0; t < W; ++t)
                     if (mg->sh[t].slot[k].got_valid) HIP_TRY(hipStreamWaitEvent(S.ctx->stream, mg->sh[t].slot[k].got, 0));
-            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 0, shift, in[s], S.slot[k].send, rows_transposed,
-                                         mul ? mul[s] : nullptr));
+            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 0, shift, in, S.slot[k].send, rows_transposed, mul));
             HIP_TRY(hipEventRecord(S.slot[k].sent, S.ctx->stream));
         }
-        return exchange(k);
+        return exchange(s, k);
     }
 
-    // add: out[s][k] = X[k] + add[s][k] (same layout as out)
-    int finish(int k, uint4* const* out, int inverse, const H256* shift, uint4* const* add = nullptr) {
-        const uint32_t W = mg->W;
-        for (uint32_t s = 0; s < W; ++s) {
-            MgShard& S = mg->sh[s];
-            HIP_TRY(hipSetDevice(S.device));
-            CtxLock lock(S.ctx->mu);
-            HIP_TRY(hipStreamWaitEvent(S.ctx->stream, S.slot[k].got, 0));
-            ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, W, s, inverse, 1, shift, S.slot[k].recv, out[s], false, nullptr,
-                                         add ? add[s] : nullptr));
-            HIP_TRY(hipEventRecord(S.slot[k].used, S.ctx->stream));
-            S.slot[k].used_valid = true;
-        }
+    // add: out[k] = X[k] + add[k] (same layout as out)
+    int finish(uint32_t s, int k, uint4* out, int inverse, const H256* shift, const uint4* add = nullptr) {
+        MgShard& S = mg->sh[s];
+        CtxLock lock(S.ctx->mu);
+        HIP_TRY(hipStreamWaitEvent(S.ctx->stream, S.slot[k].got, 0));
+        ACX_TRY(ntt_dist_step_locked(S.ctx, log_n, log_r, mg->W, s, inverse, 1, shift, S.slot[k].recv, out, false, nullptr, add));
+        HIP_TRY(hipEventRecord(S.slot[k].used, S.ctx->stream));
+        S.slot[k].used_valid = true;
         return ACX_OK;
     }
 };
 
-// run fn(shard) on one host thread per shard (host-to-device copies of pageable memory block their caller: one thread per
-// PCIe link); the first failure and its message are carried back to the calling thread
-template <class Fn>
-int mg_per_shard_threads(acx_mgpu* mg, Fn&& fn) {
-    const uint32_t W = mg->W;
-    std::vector<int> rc(W, ACX_OK);
-    std::vector<std::string> msg(W);
-    auto body = [&](uint32_t s) {
-        try {
-            rc[s] = fn(s);
-        } catch (const std::bad_alloc&) {
-            rc[s] = fail(ACX_ERR_OOM, "host allocation failed");
-        } catch (...) {
-            rc[s] = fail(ACX_ERR_INVALID_ARG, "unexpected exception");
-        }
-        if (rc[s] != ACX_OK) msg[s] = g_last_error;
-    };
-    if (W == 1) {
-        body(0);
-    } else {
-        std::vector<std::thread> th;
-        uint32_t started = 0;
-        try {
-            th.reserve(W);
-            for (; started < W; ++started) th.emplace_back(body, started);
-        } catch (...) {
-        }
-        for (uint32_t s = started; s < W; ++s) body(s);
-        for (auto& t : th) t.join();
-    }
-    for (uint32_t s = 0; s < W; ++s)
-        if (rc[s] != ACX_OK) return fail(rc[s], msg[s]);
-    return ACX_OK;
-}
-
-// replicate the witness: upload + conversion on every shard; the canonicity flag lands in the shard's CallSlot
+// Replicate the witness on every shard (dev format; the canonicity flag lands in shard 0's CallSlot, and in every shard's with
+// the host-copy modes).  mg->witness_mode (ACX_MGPU_WITNESS = broadcast | copies | pinned):
+//   broadcast  ONE host-to-device copy and ONE conversion, on shard 0; the other shards receive the converted elements over
+//              the device fabric -- ncclBroadcast on every shard's stream (xGMI), or one device copy each pulled by the shard
+//              itself with the peer-copy transport.  m * 32 bytes cross PCIe once instead of W times.
+//   copies     one pageable host-to-device copy per shard, each from its own host thread over its own PCIe link
+//   pinned     the same from registered memory: the caller's buffer is page-locked for the duration of the call
 int mg_upload_witness(acx_mgpu_r1cs* mr, const acx_fr* witness) {
     acx_mgpu* mg = mr->mg;
     mr->witness_resident = false;
     mr->h_valid = false;
-    ACX_TRY(mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+    const uint32_t W = mg->W;
+    const int mode = W == 1 ? 1 : mg->witness_mode;
+    static const CallSlot init{0ull, ~0ull, 0u, {0u, 0u, 0u}};
+    bool registered = false;
+    if (mode == 2) registered = hipHostRegister(const_cast<acx_fr*>(witness), mr->m * 32, hipHostRegisterDefault) == hipSuccess;
+    if (mode == 2 && !registered) (void)hipGetLastError();          // e.g. already registered by the caller: plain copies then
+    const int rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
         MgShard& S = mg->sh[s];
         HIP_TRY(hipSetDevice(S.device));
         CtxLock lock(S.ctx->mu);
-        static const CallSlot init{0ull, ~0ull, 0u, {0u, 0u, 0u}};
         HIP_TRY(hipMemcpyAsync(S.d_res, &init, sizeof(init), hipMemcpyHostToDevice, S.ctx->stream));
         uint4* d_w = mr->part[s].d_w;
-        HIP_TRY(hipMemcpyAsync(d_w, witness, mr->m * 32, hipMemcpyHostToDevice, S.ctx->stream));
-        return launch_convert(S.ctx, true, d_w, d_w, mr->m, (uint32_t*)(S.d_res + 2));
-    }));
+        if (mode != 0) {
+            HIP_TRY(hipMemcpyAsync(d_w, witness, mr->m * 32, hipMemcpyHostToDevice, S.ctx->stream));
+            return launch_convert(S.ctx, true, d_w, d_w, mr->m, (uint32_t*)(S.d_res + 2));
+        }
+        if (s == 0) {
+            if (!mg->rccl)                                          // peers still reading the previous witness out of shard 0's buffer
+                for (uint32_t t = 1; t < W; ++t)
+                    if (mg->sh[t].w_read_valid) HIP_TRY(hipStreamWaitEvent(S.ctx->stream, mg->sh[t].w_read, 0));
+            HIP_TRY(hipMemcpyAsync(d_w, witness, mr->m * 32, hipMemcpyHostToDevice, S.ctx->stream));
+            ACX_TRY(launch_convert(S.ctx, true, d_w, d_w, mr->m, (uint32_t*)(S.d_res + 2)));
+            if (!mg->rccl) HIP_TRY(hipEventRecord(S.w_ready, S.ctx->stream));
+        }
+        if (mg->rccl)
+            NCCL_TRY(mg, mg->api->Broadcast(mr->part[0].d_w, d_w, mr->m * 4, ncclUint64, 0, S.comm, S.ctx->stream));
+        else {
+            MG_BARRIER(mg);                                         // shard 0's w_ready is recorded
+            if (s != 0) {
+                MgShard& S0 = mg->sh[0];
+                HIP_TRY(hipStreamWaitEvent(S.ctx->stream, S0.w_ready, 0));
+                if (S0.device == S.device) HIP_TRY(hipMemcpyAsync(d_w, mr->part[0].d_w, mr->m * 32, hipMemcpyDeviceToDevice, S.ctx->stream));
+                else HIP_TRY(hipMemcpyPeerAsync(d_w, S.device, mr->part[0].d_w, S0.device, mr->m * 32, S.ctx->stream));
+                HIP_TRY(hipEventRecord(S.w_read, S.ctx->stream));
+                S.w_read_valid = true;
+            }
+        }
+        return ACX_OK;
+    });
+    if (registered) {
+        for (auto& S : mg->sh) { (void)hipSetDevice(S.device); (void)hipStreamSynchronize(S.ctx->stream); }
+        (void)hipHostUnregister(const_cast<acx_fr*>(witness));
+    }
+    ACX_TRY(rc);
     mr->witness_resident = true;
     return ACX_OK;
 }
 
 // residual launch on every shard (+ dots when the h(x) pipeline follows) and the verdict.
 // Two halves, so that h(x) can issue its whole pipeline between them and the host waits once, at the end.
-// mg_residual_enqueue: the residual launch on every shard (+ dots when the h(x) pipeline follows) and, with RCCL, THE verdict
-// collective behind it -- everything asynchronous.  mg_residual_fetch: the verdict (one wait).
-int mg_residual_enqueue(acx_mgpu_r1cs* mr, bool with_dots, bool scaled_dots = false) {
+// mg_residual_enqueue_shard: ONE shard's residual launch (+ dots when the h(x) pipeline follows) and, with RCCL, its rank of THE
+// verdict collective behind it -- everything asynchronous, on the shard's issuing thread.  mg_residual_fetch: the verdict (one wait).
+int mg_residual_enqueue_shard(acx_mgpu_r1cs* mr, uint32_t s, bool with_dots, bool scaled_dots) {
     acx_mgpu* mg = mr->mg;
     const uint32_t W = mg->W;
     const uint64_t L = (1ull << mr->log_n) / W, rw = (1ull << mr->log_r) / W;
-    for (uint32_t s = 0; s < W; ++s) {
-        MgShard& S = mg->sh[s];
-        HIP_TRY(hipSetDevice(S.device));
-        CtxLock lock(S.ctx->mu);
-        static const unsigned long long init[2] = {0ull, ~0ull};
-        HIP_TRY(hipMemcpyAsync(S.d_res, init, 16, hipMemcpyHostToDevice, S.ctx->stream));      // the canonicity flag stays
-        const auto& P = mr->part[s];
-        if (with_dots)          // the block-cyclic copy: dots in ascending row order (= ROWS transposed), first_bad through the run map
-            ACX_TRY(launch_residual(P.cyc, P.d_w, (uint64_t)s * rw, S.d_res, nullptr, P.vec, L, mr->log_r - mg_log2(W), mr->log_r,
-                                    scaled_dots ? (const uint4*)P.hscale : nullptr));
-        else
-            ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, S.d_res, nullptr, nullptr, 0));
-    }
-    if (mg->rccl) {
-        // THE verdict collective: sum of the violated-row counts, into word 4 of every shard's slot
-        NCCL_TRY(mg, mg->api->GroupStart());
-        for (auto& S : mg->sh) {
-            const ncclResult_t r = mg->api->AllReduce(S.d_res, S.d_res + 4, 1, ncclUint64, ncclSum, S.comm, S.ctx->stream);
-            if (r != ncclSuccess) { (void)mg->api->GroupEnd(); return fail(ACX_ERR_HIP, std::string("ncclAllReduce: ") + mg->api->GetErrorString(r)); }
-        }
-        NCCL_TRY(mg, mg->api->GroupEnd());
-    }
+    MgShard& S = mg->sh[s];
+    HIP_TRY(hipSetDevice(S.device));
+    CtxLock lock(S.ctx->mu);
+    static const unsigned long long init[2] = {0ull, ~0ull};
+    HIP_TRY(hipMemcpyAsync(S.d_res, init, 16, hipMemcpyHostToDevice, S.ctx->stream));      // the canonicity flag stays
+    const auto& P = mr->part[s];
+    if (with_dots)          // the block-cyclic copy: dots in ascending row order (= ROWS transposed), first_bad through the run map
+        ACX_TRY(launch_residual(P.cyc, P.d_w, (uint64_t)s * rw, S.d_res, nullptr, P.vec, L, mr->log_r - mg_log2(W), mr->log_r,
+                                scaled_dots ? (const uint4*)P.hscale : nullptr));
+    else
+        ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, S.d_res, nullptr, nullptr, 0));
+    if (mg->rccl)           // THE verdict collective: sum of the violated-row counts, into word 4 of every shard's slot
+        NCCL_TRY(mg, mg->api->AllReduce(S.d_res, S.d_res + 4, 1, ncclUint64, ncclSum, S.comm, S.ctx->stream));
     return ACX_OK;
+}
+
+int mg_residual_enqueue(acx_mgpu_r1cs* mr, bool with_dots, bool scaled_dots = false) {
+    return mg_per_shard_threads(mr->mg, [&](uint32_t s) -> int { return mg_residual_enqueue_shard(mr, s, with_dots, scaled_dots); });
 }
 
 int mg_residual_fetch(acx_mgpu_r1cs* mr, bool want_first, uint64_t* n_bad, uint64_t* first_bad, bool* noncanonical) {
@@ -433,8 +593,9 @@ int mg_residual_fetch(acx_mgpu_r1cs* mr, bool want_first, uint64_t* n_bad, uint6
     return ACX_OK;
 }
 
-int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_bad, uint64_t* first_bad, bool* noncanonical) {
+int mg_residual(acx_mgpu_r1cs* mr, bool with_dots, bool want_first, uint64_t* n_bad, uint64_t* first_bad, bool* noncanonical, MgClock* clock = nullptr) {
     ACX_TRY(mg_residual_enqueue(mr, with_dots));
+    if (clock) clock->issued();
     return mg_residual_fetch(mr, want_first, n_bad, first_bad, noncanonical);
 }
 
@@ -565,6 +726,7 @@ void mg_free_r1cs(acx_mgpu_r1cs* mr) {
         if (p.slab) acx_r1cs_destroy(p.slab);                         // synchronises that device
         if (p.cyc) acx_r1cs_destroy(p.cyc);
         if (p.full) acx_r1cs_destroy(p.full);
+        if (p.cols) acx_r1cs_destroy(p.cols);
         (void)hipSetDevice(mg->sh[s].device);
         if (p.d_w) (void)hipFree(p.d_w);
         if (p.vec) (void)hipFree(p.vec);
@@ -673,10 +835,9 @@ int mg_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* const mats[3], 
     return ACX_OK;
 }
 
-// Per-wire polynomials (`createPolynomialsFFT`, src/QAP.hs:512-525) shard by WIRE with no communication: a
-// column's interpolation needs every row of its matrix, so each shard takes a copy of the whole system.  Only callers
-// of acx_mgpu_qap_columns pay for that, on their first call: the slabs are read back from the devices (canonical CSR,
-// acx_r1cs_export), joined on the host and loaded on every shard by one thread each.
+// A copy of the WHOLE system on shard 0 (every_shard = false is the only use left): acx_mgpu_qap_h of a transform size the
+// distributed four-step form does not cover answers from one device.  The slabs are read back from the devices (canonical CSR,
+// acx_r1cs_export), joined on the host and loaded.
 int mg_ensure_replicas(acx_mgpu_r1cs* mr, bool every_shard = true) {
     acx_mgpu* mg = mr->mg;
     const uint32_t W = mg->W;
@@ -725,7 +886,141 @@ int mg_ensure_replicas(acx_mgpu_r1cs* mr, bool every_shard = true) {
     });
 }
 
-// verificationWitnessZk over the shards on the resident witness; h stays on the devices in COLS ownership
+// Per-wire polynomials (`createPolynomialsFFT`, src/QAP.hs:512-525) shard by WIRE with no communication, and a
+// wire's interpolation needs its own COLUMN of every row, nothing else.  So each shard holds the column view of its wires only:
+// wire w belongs to shard (w / kMgColBlock) mod W (block-cyclic: any request of a few hundred consecutive wires spreads over all
+// devices), numbered locally (w / (kMgColBlock W)) * kMgColBlock + w mod kMgColBlock.  All shards together hold every entry
+// ONCE (40 bytes each: row, column, value) -- the first version gave every device a copy of the whole system.  Built on the
+// first call, one matrix at a time: every shard's row slab is read back (canonical CSR), a counting sort by column makes the
+// global column view on the host, every shard takes its blocks.
+int mg_ensure_col_slices(acx_mgpu_r1cs* mr) {
+    acx_mgpu* mg = mr->mg;
+    const uint32_t W = mg->W;
+    if (!mr->sharded || mr->part[0].cols) return ACX_OK;
+    const uint64_t m = mr->m, B = kMgColBlock;
+    auto owner = [&](uint64_t w) { return (uint32_t)((w / B) % W); };
+    auto local = [&](uint64_t w) { return (w / (B * W)) * B + w % B; };
+    std::vector<uint64_t> m_local(W, 0);
+    for (uint64_t j = 0; j * B < m; ++j) m_local[j % W] += std::min<uint64_t>(B, m - j * B);
+    std::vector<std::array<HostCsc, 3>> slices(W);
+    for (int k = 0; k < 3; ++k) {
+        // read the slabs back: rows [row0, row0 + rows) of matrix k per shard
+        std::vector<std::vector<uint32_t>> rp(W), cl(W);
+        std::vector<std::vector<acx_fr>> vl(W);
+        ACX_TRY(mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+            const auto& P = mr->part[s];
+            uint64_t rows = 0, z[3] = {0, 0, 0};
+            ACX_TRY(acx_r1cs_dims(P.slab, &rows, nullptr, nullptr, z));
+            rp[s].resize(rows + 1);
+            cl[s].resize(z[k]);
+            vl[s].resize(z[k]);
+            return acx_r1cs_export(P.slab, k, rp[s].data(), cl[s].data(), vl[s].data());
+        }));
+        // counting sort by column over all slabs -> global colptr; then every shard's blocks in local numbering
+        std::vector<uint64_t> colptr(m + 1, 0);
+        for (uint32_t s = 0; s < W; ++s)
+            for (uint32_t c : cl[s]) ++colptr[(uint64_t)c + 1];
+        for (uint64_t w = 0; w < m; ++w) colptr[w + 1] += colptr[w];
+        for (uint32_t s = 0; s < W; ++s) {                           // local colptr of every shard
+            HostCsc& H = slices[s][k];
+            H.colptr.assign(m_local[s] + 1, 0);
+        }
+        for (uint64_t w = 0; w < m; ++w) slices[owner(w)][k].colptr[local(w) + 1] = (uint32_t)(colptr[w + 1] - colptr[w]);
+        for (uint32_t s = 0; s < W; ++s) {
+            HostCsc& H = slices[s][k];
+            uint64_t acc = 0;
+            for (uint64_t i = 0; i < m_local[s]; ++i) { acc += H.colptr[i + 1]; if (acc >= 0xffffffffull) return fail(ACX_ERR_TOO_LARGE, "column slice has 2^32 entries or more"); H.colptr[i + 1] = (uint32_t)acc; }
+            H.rowidx.resize(acc); H.colid.resize(acc); H.val.resize(acc);
+        }
+        std::vector<uint32_t> cursor(m, 0);
+        for (uint32_t s = 0; s < W; ++s) {                           // slabs in shard order = ascending global rows
+            const uint64_t row0 = mr->part[s].row0;
+            const uint64_t rows = rp[s].size() - 1;
+            for (uint64_t i = 0; i < rows; ++i)
+                for (uint32_t e = rp[s][i]; e < rp[s][i + 1]; ++e) {
+                    const uint64_t w = cl[s][e];
+                    HostCsc& H = slices[owner(w)][k];
+                    const uint64_t lw = local(w), dst = (uint64_t)H.colptr[lw] + cursor[w]++;
+                    H.rowidx[dst] = (uint32_t)(row0 + i);
+                    H.colid[dst] = (uint32_t)lw;
+                    H.val[dst] = vl[s][e];
+                }
+        }
+    }
+    const int rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+        return r1cs_column_slice_from_host(mg->sh[s].ctx, mr->n, mr->log_n, m_local[s], slices[s].data(), &mr->part[s].cols);
+    });
+    if (rc != ACX_OK)                                               // all or none: a retry starts clean
+        for (uint32_t s = 0; s < W; ++s)
+            if (mr->part[s].cols) { acx_r1cs_destroy(mr->part[s].cols); mr->part[s].cols = nullptr; }
+    return rc;
+}
+
+// verificationWitnessZk over the shards on the resident witness; h stays on the devices in COLS ownership.
+// The whole pipeline of ONE shard -- residual launch, six transforms (twelve local steps, six exchanges), the elementwise tail --
+// is issued by that shard's own thread (mg_qap_h_issue_shard); the calling thread then waits once, for the verdict.
+struct MgHArgs {
+    const H256* dl;
+    bool zk, fusedh;
+    H256 g, zinv, mzinv;
+};
+
+int mg_qap_h_issue_shard(acx_mgpu_r1cs* mr, uint32_t s, const MgHArgs& A) {
+    acx_mgpu* mg = mr->mg;
+    const uint32_t W = mg->W;
+    const uint64_t N = 1ull << mr->log_n, L = N / W;
+    MgShard& S = mg->sh[s];
+    const HostField& hf = S.ctx->hf;
+    HIP_TRY(hipSetDevice(S.device));
+    uint4* v = mr->part[s].vec;
+    auto at = [&](uint64_t off) { return v + 2 * off * L; };
+    // vec: dots k at k L (ROWS), coefficients k at (3 + k) L (COLS), pointwise product at 6 L (ROWS), h at 7 L (COLS)
+    ACX_TRY(mg_residual_enqueue_shard(mr, s, true, A.fusedh));      // the verdict is fetched after the whole pipeline has been issued: one wait
+    MgNtt nt(mg, mr->log_n, mr->log_r);
+    // Software pipeline over the three vectors (qap_h_dev_locked's sequence, sharded): vector k's exchange runs on the
+    // exchange stream under vector k+1's local step, and a vector's coset transform starts as soon as its inverse one is
+    // complete -- of the six all-to-alls only the last has no local work to hide behind.
+    for (int k = 0; k < 3; ++k) ACX_TRY(nt.begin(s, k, at(k), 1, nullptr, true));              // dots: ascending row order
+    for (int k = 0; k < 3; ++k) {
+        ACX_TRY(nt.finish(s, k, at(3 + k), 1, nullptr));
+        if (k < 2) ACX_TRY(nt.begin(s, k, at(3 + k), 0, &A.g));
+    }
+    for (int k = 0; k < 2; ++k) ACX_TRY(nt.finish(s, k, at(k), 0, &A.g));
+    if (A.fusedh) {
+        // without the zero-knowledge terms 1/z and -1/z ride on the stored dots, the last transform takes (L/z) * R as its first
+        // step loads the points and adds -O/z behind its closing step (qap_h_dev_locked's fused form, sharded)
+        ACX_TRY(nt.begin(s, 0, at(0), 1, &A.g, false, at(1)));
+        return nt.finish(s, 0, at(7), 1, &A.g, at(5));
+    }
+    {
+        CtxLock lock(S.ctx->mu);
+        DISPATCH_FIELD(S.ctx, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(S.ctx, L)), dim3(kBlock), 0, S.ctx->stream, (const uint4*)v,
+                                                 (const uint4*)(v + 2 * L), (const uint4*)nullptr, v + 2 * 6 * L, L, dev_arg(hf, A.zinv), 0u));
+        HIP_TRY(hipGetLastError());
+    }
+    ACX_TRY(nt.begin(s, 0, at(6), 1, &A.g));
+    ACX_TRY(nt.finish(s, 0, at(7), 1, &A.g));
+    CtxLock lock(S.ctx->mu);
+    uint4 *h = at(7), *L0 = at(3), *R0 = at(4), *O0 = at(5);
+    if (A.zk) {
+        // (L0+d1 T)(R0+d2 T) - (O0+d3 T) = T (h0 + d1 R0 + d2 L0 + d1 d2 T - d3), T = x^N - 1 (src/QAP.hs:315-323): the
+        // elementwise part is layout agnostic (h, L0, R0, O0 share the COLS ownership); coefficient 0 lives on shard 0
+        // at local index 0 and coefficient N (= d1 d2) is appended by the fetch
+        const H256 d12 = hf.mul(A.dl[0], A.dl[1]);
+        DISPATCH_FIELD(S.ctx, {
+            hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(S.ctx, L)), dim3(kBlock), 0, S.ctx->stream, h, (const uint4*)R0, (const uint4*)L0,
+                               (const uint4*)O0, L, dev_arg(hf, A.dl[0]), dev_arg(hf, A.dl[1]), dev_arg(hf, A.mzinv));
+            if (s == 0) hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, S.ctx->stream, h, ~(u64)0, dev_arg(hf, hf.add(d12, A.dl[2])),
+                                           dev_arg(hf, hf.zero()));
+        });
+    } else {
+        DISPATCH_FIELD(S.ctx, hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(S.ctx, L)), dim3(kBlock), 0, S.ctx->stream, h, (const uint4*)nullptr,
+                                                 (const uint4*)nullptr, (const uint4*)O0, L, dev_arg(hf, A.mzinv), dev_arg(hf, A.mzinv), dev_arg(hf, A.mzinv)));
+    }
+    HIP_TRY(hipGetLastError());
+    return ACX_OK;
+}
+
 int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
     acx_mgpu* mg = mr->mg;
     const uint32_t W = mg->W;
@@ -741,70 +1036,21 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
             HIP_TRY(hipMalloc((void**)&mr->part[s].vec, 8 * L * 32));
         }
     mr->h_valid = false;
-    const bool zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
-    // without the zero-knowledge terms 1/z and -1/z ride on the stored dots, the last transform takes (L/z) * R as its first
-    // step loads the points and adds -O/z behind its closing step (qap_h_dev_locked's fused form, sharded)
-    const bool fusedh = !zk && mr->part[0].hscale != nullptr;
-    ACX_TRY(mg_residual_enqueue(mr, true, fusedh)); // the verdict is fetched after the whole pipeline has been issued: one wait
-    const H256 g = hf.generator();
-    MgNtt nt(mg, mr->log_n, mr->log_r);
-    auto ptrs = [&](uint64_t off) { std::vector<uint4*> v(W); for (uint32_t s = 0; s < W; ++s) v[s] = mr->part[s].vec + 2 * off; return v; };
-    // vec: dots k at k L (ROWS), coefficients k at (3 + k) L (COLS), pointwise product at 6 L (ROWS), h at 7 L (COLS)
-    // Software pipeline over the three vectors (qap_h_dev_locked's sequence, sharded): vector k's exchange runs on the
-    // exchange streams under vector k+1's local step, and a vector's coset transform starts as soon as its inverse one is
-    // complete -- of the six all-to-alls only the last has no local work to hide behind.
-    for (int k = 0; k < 3; ++k) ACX_TRY(nt.begin(k, ptrs((uint64_t)k * L).data(), 1, nullptr, true));     // dots: ascending row order
-    for (int k = 0; k < 3; ++k) {
-        ACX_TRY(nt.finish(k, ptrs((3 + (uint64_t)k) * L).data(), 1, nullptr));
-        if (k < 2) ACX_TRY(nt.begin(k, ptrs((3 + (uint64_t)k) * L).data(), 0, &g));
-    }
-    for (int k = 0; k < 2; ++k) ACX_TRY(nt.finish(k, ptrs((uint64_t)k * L).data(), 0, &g));
-    const H256 zinv = hf.inv(hf.sub(hf.pow_u64(g, N), hf.one()));
-    const H256 mzinv = hf.sub(hf.zero(), zinv);
-    if (fusedh) {
-        ACX_TRY(nt.begin(0, ptrs(0).data(), 1, &g, false, ptrs(L).data()));
-        ACX_TRY(nt.finish(0, ptrs(7 * L).data(), 1, &g, ptrs(5 * L).data()));
-    } else {
-        for (uint32_t s = 0; s < W; ++s) {
-            MgShard& S = mg->sh[s];
-            HIP_TRY(hipSetDevice(S.device));
-            CtxLock lock(S.ctx->mu);
-            uint4* v = mr->part[s].vec;
-            DISPATCH_FIELD(S.ctx, hipLaunchKernelGGL((k_pointwise_h<F>), dim3(grid_for(S.ctx, L)), dim3(kBlock), 0, S.ctx->stream, (const uint4*)v,
-                                                     (const uint4*)(v + 2 * L), (const uint4*)nullptr, v + 2 * 6 * L, L, dev_arg(hf, zinv), 0u));
-            HIP_TRY(hipGetLastError());
-        }
-        ACX_TRY(nt.begin(0, ptrs(6 * L).data(), 1, &g));
-        ACX_TRY(nt.finish(0, ptrs(7 * L).data(), 1, &g));
-    }
-    for (uint32_t s = 0; s < W && !fusedh; ++s) {
-        MgShard& S = mg->sh[s];
-        HIP_TRY(hipSetDevice(S.device));
-        CtxLock lock(S.ctx->mu);
-        uint4* v = mr->part[s].vec;
-        uint4 *h = v + 2 * 7 * L, *L0 = v + 2 * 3 * L, *R0 = v + 2 * 4 * L, *O0 = v + 2 * 5 * L;
-        if (zk) {
-            // (L0+d1 T)(R0+d2 T) - (O0+d3 T) = T (h0 + d1 R0 + d2 L0 + d1 d2 T - d3), T = x^N - 1 (src/QAP.hs:315-323): the
-            // elementwise part is layout agnostic (h, L0, R0, O0 share the COLS ownership); coefficient 0 lives on shard 0
-            // at local index 0 and coefficient N (= d1 d2) is appended by the fetch
-            const H256 d12 = hf.mul(dl[0], dl[1]);
-            DISPATCH_FIELD(S.ctx, {
-                hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(S.ctx, L)), dim3(kBlock), 0, S.ctx->stream, h, (const uint4*)R0, (const uint4*)L0,
-                                   (const uint4*)O0, L, dev_arg(hf, dl[0]), dev_arg(hf, dl[1]), dev_arg(hf, mzinv));
-                if (s == 0) hipLaunchKernelGGL((k_h_fix<F>), dim3(1), dim3(64), 0, S.ctx->stream, h, ~(u64)0, dev_arg(hf, hf.add(d12, dl[2])),
-                                               dev_arg(hf, hf.zero()));
-            });
-        } else {
-            DISPATCH_FIELD(S.ctx, hipLaunchKernelGGL((k_axpy3<F>), dim3(grid_for(S.ctx, L)), dim3(kBlock), 0, S.ctx->stream, h, (const uint4*)nullptr,
-                                                     (const uint4*)nullptr, (const uint4*)O0, L, dev_arg(hf, mzinv), dev_arg(hf, mzinv), dev_arg(hf, mzinv)));
-        }
-        HIP_TRY(hipGetLastError());
-    }
+    MgClock clock(mg);
+    MgHArgs A;
+    A.dl = dl;
+    A.zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
+    A.fusedh = !A.zk && mr->part[0].hscale != nullptr;
+    A.g = hf.generator();
+    A.zinv = hf.inv(hf.sub(hf.pow_u64(A.g, N), hf.one()));
+    A.mzinv = hf.sub(hf.zero(), A.zinv);
+    ACX_TRY(mg_per_shard_threads(mg, [&](uint32_t s) -> int { return mg_qap_h_issue_shard(mr, s, A); }));
     uint64_t n_bad = 0, first = 0;
     bool noncanon = false;
+    clock.issued();
     ACX_TRY(mg_residual_fetch(mr, false, &n_bad, &first, &noncanon));
     if (noncanon) return fail(ACX_ERR_NONCANONICAL, "element >= p");
-    mr->h_top = zk ? hf.mul(dl[0], dl[1]) : hf.zero();
+    mr->h_top = A.zk ? hf.mul(dl[0], dl[1]) : hf.zero();
     mr->h_valid = true;
     *ok = n_bad == 0;
     return ACX_OK;
@@ -826,6 +1072,7 @@ extern "C" {
 void acx_mgpu_destroy(acx_mgpu* mg) {
     if (!mg) return;
     DevGuard dg;
+    if (mg->pool) mg->pool->shutdown();
     for (auto& S : mg->sh) {
         if (!S.ctx) continue;                                      // creation stopped before this shard: nothing to release
         (void)hipSetDevice(S.device);
@@ -839,6 +1086,8 @@ void acx_mgpu_destroy(acx_mgpu* mg) {
             if (sl.used) (void)hipEventDestroy(sl.used);
         }
         if (S.io) (void)hipFree(S.io);
+        if (S.w_ready) (void)hipEventDestroy(S.w_ready);
+        if (S.w_read) (void)hipEventDestroy(S.w_read);
         if (S.d_res) (void)hipFree(S.d_res);
         if (S.xstream) (void)hipStreamDestroy(S.xstream);
         if (S.ctx) acx_ctx_destroy(S.ctx);
@@ -876,6 +1125,19 @@ int acx_mgpu_create(int field, const int* device_ids, uint32_t n_devices, acx_mg
                 HIP_TRY(hipEventCreateWithFlags(&sl.got, hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&sl.used, hipEventDisableTiming));
             }
+            HIP_TRY(hipEventCreateWithFlags(&S.w_ready, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.w_read, hipEventDisableTiming));
+        }
+        if (const char* wm = std::getenv("ACX_MGPU_WITNESS")) {
+            const std::string m(wm);
+            if (m == "broadcast") mg->witness_mode = 0;
+            else if (m == "copies") mg->witness_mode = 1;
+            else if (m == "pinned") mg->witness_mode = 2;
+            else return fail(ACX_ERR_INVALID_ARG, "ACX_MGPU_WITNESS must be broadcast, copies or pinned");
+        }
+        if (n_devices > 1) {                                        // one issuing thread per shard for the life of the handle
+            mg->pool.reset(new MgPool());
+            mg->pool->start(n_devices, std::vector<int>(device_ids, device_ids + n_devices));
         }
         if (mg->rccl) {
             std::string why;
@@ -916,6 +1178,13 @@ int acx_mgpu_info(const acx_mgpu* mg, uint32_t* n_devices, int* transport, uint3
 }
 
 acx_ctx* acx_mgpu_ctx(acx_mgpu* mg, uint32_t shard) { return (mg && shard < mg->W) ? mg->sh[shard].ctx : nullptr; }
+
+// development aid (not in include/acx.h): {issue seconds, total seconds} of the last verify / h(x) call on the handle
+int acx_mgpu_debug_times(acx_mgpu* mg, double out[2]) {
+    if (!mg || !out) return ACX_ERR_INVALID_ARG;
+    out[0] = mg->last_issue_s; out[1] = mg->last_total_s;
+    return ACX_OK;
+}
 
 int acx_mgpu_set_shard_threshold(acx_mgpu* mg, uint32_t log_n) {
     if (!mg) return fail(ACX_ERR_INVALID_ARG, "null handle");
@@ -1043,10 +1312,11 @@ int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* mr, const acx_fr* witness, int* ok, uint
         if (!mr->sharded) return acx_r1cs_verify(mr->whole, witness, ok, n_bad, first_bad);
         std::lock_guard<std::mutex> g(mr->mg->mu);
         DevGuard dg;
+        MgClock clock(mr->mg);
         ACX_TRY(mg_upload_witness(mr, witness));
         uint64_t bad = 0, first = ~0ull;
         bool noncanon = false;
-        ACX_TRY(mg_residual(mr, false, first_bad != nullptr, &bad, &first, &noncanon));
+        ACX_TRY(mg_residual(mr, false, first_bad != nullptr, &bad, &first, &noncanon, &clock));
         if (noncanon) { mr->witness_resident = false; return fail(ACX_ERR_NONCANONICAL, "element >= p"); }
         *ok = bad == 0;
         if (n_bad) *n_bad = bad;
@@ -1065,14 +1335,14 @@ int acx_mgpu_r1cs_verify_enqueue(acx_mgpu_r1cs* mr, uint32_t slot) {
         std::lock_guard<std::mutex> g(mg->mu);
         if (!mr->witness_resident) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
         DevGuard dg;
-        for (uint32_t s = 0; s < mg->W; ++s) {
+        MgClock clock(mg);
+        return mg_per_shard_threads(mg, [&](uint32_t s) -> int {
             MgShard& S = mg->sh[s];
             HIP_TRY(hipSetDevice(S.device));
             CtxLock lock(S.ctx->mu);
             const auto& P = mr->part[s];
-            ACX_TRY(launch_residual(P.slab, P.d_w, P.row0, P.ring + 2 * slot, nullptr, nullptr, 0));
-        }
-        return ACX_OK;
+            return launch_residual(P.slab, P.d_w, P.row0, P.ring + 2 * slot, nullptr, nullptr, 0);
+        });
     });
 }
 
@@ -1324,14 +1594,23 @@ int acx_mgpu_qap_columns(acx_mgpu_r1cs* mr, int matrix, uint64_t wire_begin, uin
         acx_mgpu* mg = mr->mg;
         std::lock_guard<std::mutex> g(mg->mu);
         DevGuard dg;
-        ACX_TRY(mg_ensure_replicas(mr));
-        // contiguous wire ranges of equal size, one per shard, straight into the caller's buffers: no exchange at all
-        const uint64_t N = 1ull << mr->log_n, W = mg->W;
-        return mg_per_shard_threads(mg, [&](uint32_t s) -> int {
-            const uint64_t w0 = wire_count * s / W, w1 = wire_count * (s + 1) / W;
-            if (w0 == w1) return ACX_OK;
-            return acx_qap_columns(mr->part[s].full, matrix, wire_begin + w0, w1 - w0, out + w0 * N, out_len ? out_len + w0 : nullptr);
+        ACX_TRY(mg_ensure_col_slices(mr));
+        // every shard interpolates the blocks of the range it owns, straight into the caller's buffers: no exchange at all.
+        // Device-side batches are bounded so that all shards together stage at most 2 x 256 MiB of coefficients (at least one
+        // column each), and the staging is released when the call returns (W contexts may share one device).
+        const uint64_t N = 1ull << mr->log_n, W = mg->W, B = kMgColBlock, wire_end = wire_begin + wire_count;
+        const uint64_t batch = std::max<uint64_t>(N * 32, (256ull << 20) / W);
+        const int rc = mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+            for (uint64_t j = wire_begin / B; j * B < wire_end; ++j) {
+                if (j % W != s) continue;
+                const uint64_t lo = std::max(wire_begin, j * B), hi = std::min(wire_end, (j + 1) * B);
+                ACX_TRY(qap_columns_host(mr->part[s].cols, matrix, (j / W) * B + (lo - j * B), hi - lo, out + (lo - wire_begin) * N,
+                                         out_len ? out_len + (lo - wire_begin) : nullptr, batch));
+            }
+            return ACX_OK;
         });
+        for (auto& S : mg->sh) ctx_trim_scratch(S.ctx);
+        return rc;
     });
 }
 
@@ -1358,9 +1637,12 @@ int acx_mgpu_ntt(acx_mgpu* mg, uint32_t log_n, int inverse, const acx_fr* shift,
         // forward: COLS -> ROWS; inverse: ROWS -> COLS
         if (!inverse) ACX_TRY(mg_push_natural(mg, in, R, C / W, C, src.data())); else ACX_TRY(mg_push_natural(mg, in, C, R / W, R, src.data()));
         ACX_TRY(mg_check_canonical(mg));
-        MgNtt nt(mg, log_n, log_r);
-        ACX_TRY(nt.begin(0, src.data(), inverse, shift ? &sh : nullptr));
-        ACX_TRY(nt.finish(0, dst.data(), inverse, shift ? &sh : nullptr));
+        ACX_TRY(mg_per_shard_threads(mg, [&](uint32_t s) -> int {
+            HIP_TRY(hipSetDevice(mg->sh[s].device));
+            MgNtt nt(mg, log_n, log_r);
+            ACX_TRY(nt.begin(s, 0, src[s], inverse, shift ? &sh : nullptr));
+            return nt.finish(s, 0, dst[s], inverse, shift ? &sh : nullptr);
+        }));
         if (!inverse) return mg_fetch_natural(mg, dst.data(), C, R / W, R, out);
         return mg_fetch_natural(mg, dst.data(), R, C / W, C, out);
     });

@@ -300,8 +300,8 @@ def test_mgpu_calls_from_several_threads(acx, request, devices):
 @pytest.mark.parametrize("field", ["bn254", "bls12_381"])
 def test_mgpu_qap_columns_shared_out_by_wire(acx, request, field, devices):
     """createPolynomialsFFT (/root/reference/src/QAP.hs:512-525) behind the multi-GPU handle: wires shared out over the
-    shards, every shard interpolating its wires on its own copy of the whole system (built on the first call from the
-    row slabs) -- bit-equal to the C oracle and to acx_qap_columns of one GPU, coefficients and stripped lengths, for
+    shards (block-cyclic by wire), every shard interpolating its wires on the column view of those wires alone (built on
+    the first call from the row slabs) -- bit-equal to the C oracle and to acx_qap_columns of one GPU, coefficients and stripped lengths, for
     ranges that divide evenly, ragged ones, fewer wires than shards, and the gate mix whose Split rows are long."""
     synth = acx.synth
     mg = _mg(acx, request, field, devices)
@@ -314,7 +314,8 @@ def test_mgpu_qap_columns_shared_out_by_wire(acx, request, field, devices):
     mr = mg.from_circuit(s.circuit)
     r1 = s.circuit.to_r1cs(ctx1)
     assert mr.n_shards == len(devices)
-    for k, w0, cnt in ((0, 0, 64), (1, 17, 37), (2, mr.m - 5, 5), (0, 3, 3), (1, 200, 1)):
+    # (wires are owned block-cyclically, 64 per block: ranges inside one block, across several, ending on and off a block edge)
+    for k, w0, cnt in ((0, 0, 64), (1, 17, 37), (2, mr.m - 5, 5), (0, 3, 3), (1, 200, 1), (0, 50, 300), (2, 63, 2), (1, 128, 512), (0, 0, min(mr.m, 1500))):
         cols, lens = mr.qap_columns(k, w0, cnt)
         want = orc.qap_columns(n, mr.log_n, mats[k], w0, cnt, nthreads=8)
         one, one_lens = r1.qap_columns(k, w0, cnt)
@@ -330,6 +331,45 @@ def test_mgpu_qap_columns_shared_out_by_wire(acx, request, field, devices):
         mr.qap_columns(0, mr.m - 2, 3)
     with pytest.raises(acx.AcxError):
         mr.qap_columns(3, 0, 1)
+
+
+def test_mgpu_qap_columns_device_memory_is_one_system_not_W(acx, request):
+    """Eight shards on one device: what acx_mgpu_qap_columns leaves on the device for its column views must stay below 1.5x
+    ONE system (every entry is held once, 40 bytes, by the shard that owns its wire) -- the first version gave each of the
+    eight shards a copy of the whole system.  hipMemGetInfo around a single-GPU load of the same system is the yardstick."""
+    import gc
+    import torch
+    synth = acx.synth
+    ctx1 = request.getfixturevalue("ctx_bn254")
+    s = synth.mulgraph(1 << 18, seed=0xC015)
+    mats = s.rows()
+
+    def free_bytes():
+        gc.collect()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    f0 = free_bytes()
+    r1 = s.circuit.to_r1cs(ctx1)
+    ctx1.sync()
+    one_system = f0 - free_bytes()
+    r1.close()
+    assert one_system > 50e6
+    mg = acx.MultiGpu("bn254", [0] * 8)
+    mr = mg.from_circuit(s.circuit)
+    assert mr.n_shards == 8
+    mr.verify(s.witness())                       # everything verify needs exists before the measurement
+    f1 = free_bytes()
+    cols, lens = mr.qap_columns(0, 1000, 24)
+    grown = f1 - free_bytes()
+    orc = _orc(request, "bn254")
+    assert np.array_equal(cols, orc.qap_columns(mr.n, mr.log_n, mats[0], 1000, 24, nthreads=8))
+    assert grown <= 1.5 * one_system, (grown, one_system)
+    f2 = free_bytes()
+    mr.qap_columns(2, 5000, 200)                 # later calls add nothing that stays
+    assert f2 - free_bytes() <= 0.05 * one_system
+    mr.close()
+    mg.close()
 
 
 def test_mgpu_qap_columns_gate_mix_and_small_system(acx, request):
