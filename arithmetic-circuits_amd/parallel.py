@@ -479,7 +479,7 @@ class DistributedQapH:
     the points and adds -O / z (coefficient form, COLS) behind the closing multiplication of its second step: h's
     coefficients in COLS layout (rank g holds h[i1*C + g*C/W + i2l]).  O(x) never needs its coset evaluations -- the
     transforms are linear and icoset(coset(O)) = O -- so there are six all-to-alls, not seven, one verdict all-reduce, and
-    no elementwise pass outside the transforms (DESIGN.md section 4 "h(x) in round 3")."""
+    no elementwise pass outside the transforms (history: profiles/HISTORY.md "h(x) in round 3")."""
 
     def __init__(self, sharded: ShardedR1CS, ntt: DistributedNTT, generator: int):
         assert sharded.rows.shape[0] == ntt.local

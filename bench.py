@@ -10,7 +10,12 @@ device-resident witnesses: 2^21 constraints per GPU per step, ~520 MB of constra
 configs[3]); the violated-row counts are combined by ONE RCCL all-reduce per 8 steps, issued
 asynchronously on a double-buffered ring of result slots.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field)."""
+Beside the headline, rank 0 measures one parity-gated object per config of BASELINE.json -- `reference_bench` (configs[0]: the
+reference's own four criterion benchmarks of bench/Circuit.hs:26-36 through the C ABI), `ntt` / `qap_h` / `load` / `qap_columns`
+(configs[2]), `e2e` (the host-buffer boundary, PCIe included), `bls12_381` (configs[4]), `r1cs_small_coeff`, `cpu_baseline` --
+each under guard(): a failure becomes an entry of "errors", the line is always printed.  --only / --skip select them.
+
+Prints ONE JSON line on rank 0."""
 import argparse
 import importlib
 import json
@@ -454,7 +459,7 @@ def bench_load(c3):
 def bench_qap_h(ctx, stream, c3, reps=10, prewarm=0.25):
     """configs[2]'s third C3 metric: the h(x) pipeline of verificationWitness (src/QAP.hs:309-327) on a
     2^20-constraint mulgraph system, device resident (witness in, N+1 coefficients out): residual dots,
-    3 iNTT, 2 coset NTT (L, R), pointwise, coset iNTT, minus O / z in coefficient form -- six transforms (DESIGN.md section 6).
+    3 iNTT, 2 coset NTT (L, R), pointwise, coset iNTT, minus O / z in coefficient form -- six transforms (DESIGN.md section 4).
     Parity gate: every coefficient against the C oracle (which runs the textbook seven)."""
     from oracle.c_oracle import COracle
     field, log_n = c3.field, c3.log_n

@@ -371,8 +371,11 @@ void acx_batch_destroy(acx_batch* batch);
  * `verificationWitness` (src/QAP.hs:292-327) -- so a drop-in host reaches the GPUs of a node through THIS handle, with the
  * same call shapes as the single-GPU entry points and nothing else to bind: the library shards the constraint rows over the
  * devices (block-cyclic, SURVEY.md 8e: shard g owns the rows k with (k mod R) in block g of R / n_devices, N = R * C), replicates
- * the witness (one host-to-device copy per GPU), and issues the collectives itself over RCCL: ONE ncclAllReduce for the
- * verdict of a check, ONE ncclAllToAll per transform (six per h(x)), overlapped with the local steps on a second stream per GPU.
+ * the witness (ONE host-to-device copy and conversion, then ncclBroadcast over the fabric; ACX_MGPU_WITNESS=copies|pinned: one
+ * host-to-device copy per GPU instead, from pageable or from page-locked memory), and issues the collectives itself over RCCL:
+ * ONE ncclAllReduce for the verdict of a check, ONE ncclAllToAll per transform (six per h(x)), overlapped with the local steps
+ * on a second stream per GPU.  Every GPU has its own issuing host thread for the life of the handle (its own communicator:
+ * nothing crosses threads on the host), so the API calls of the N per-GPU pipelines are made side by side.
  * BASELINE.json configs[3] (2^24 constraints over 8 GPUs) is `acx_mgpu_create(field, {0..7}, 8, &mg)` + the calls below.
  *
  * device_ids: n_devices (a power of two, <= 64) HIP device ordinals.  Distinct ids: RCCL (bound with dlopen here, so a
@@ -427,9 +430,11 @@ int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* r, uint64_t count, const acx_fr* wi
 int acx_mgpu_qap_h(acx_mgpu_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok);
 /* `createPolynomialsFFT primRoots genQap` (src/QAP.hs:512-525) for a wire range of one matrix, the wires shared out over
  * the devices (columns are independent: no exchange at all): arguments and results of acx_qap_columns, every
- * device writing its wires' coefficients straight into `out`.  A column's interpolation needs every row of its matrix, so
- * the FIRST call gives every device a copy of the whole system (read back from the row slabs; kept until
- * acx_mgpu_r1cs_destroy) -- callers that only verify or compute h(x) never pay for it. */
+ * device writing its wires' coefficients straight into `out`.  Wires are owned block-cyclically (64 consecutive wires per
+ * block, block j on device j mod n_devices), so any request of a few hundred wires spreads over all devices.  A column's
+ * interpolation needs its own column of every row and nothing else: the FIRST call builds, on every device, the column view
+ * of THAT device's wires (from the row slabs read back; every entry of the system is then held once more, 40 bytes, by
+ * exactly one device; kept until acx_mgpu_r1cs_destroy) -- callers that only verify or compute h(x) never pay for it. */
 int acx_mgpu_qap_columns(acx_mgpu_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out, uint64_t* out_len);
 /* `FFT.fft` / `FFT.interpolate` (galois-fft; src/QAP.hs:521-524) of ONE 2^log_n-point vector spread over the devices: host data
  * in natural order in and out, arguments of acx_ntt with batch = 1. */

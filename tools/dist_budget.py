@@ -6,7 +6,7 @@ row source, and the all-to-all moves a known number of bytes.  Prints microsecon
 libacx's stream) and the exchange volume, from which the 8-GPU time of one distributed h(x) follows:
 
     t = residual_dots_h + 3 * (inv0t + inv1) + 2 * (fwd0c + fwd1) + (inv0m + inv1ca) + 6 * exchange + all-reduce
-(six transforms: O(x) stays in coefficient form, DESIGN.md section 6; the rank's rows are loaded in ascending order, so the three
+(six transforms: O(x) stays in coefficient form, DESIGN.md section 4; the rank's rows are loaded in ascending order, so the three
 inverse transforms of the dots start from the transposed ROWS block: inv0t; 1/z and -1/z ride on the stored dots, the last
 transform takes the product L * R on the way in (inv0m) and adds -O/z on the way out (inv1ca): no elementwise pass is left.
 Round 2's sequence -- residual_dots, pointwise, inv0 + inv1c, sub_o -- is printed beside it.)

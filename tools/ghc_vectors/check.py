@@ -10,7 +10,7 @@ sdiehl/arithmetic-circuits v0.2.0 on a machine with GHC) with this repository's 
   * verifyAssignment Bools                    vs  "valid"
   * aeson encodings of the Example.hs program / assignment vs tests/golden/aeson_example_*.json
 Any mismatch names the convention that differs (point order, padding, root table, JSON shape): that is the one
-piece of parity this build could not pin without GHC (DESIGN.md section 5).  Exit 0 = the derived fixtures ARE the
+piece of parity this build could not pin without GHC (DESIGN.md section 7).  Exit 0 = the derived fixtures ARE the
 library's outputs."""
 import json
 import os
