@@ -5,6 +5,8 @@
 // one-call shape (mgpu.inc.h, included at the end of this file).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -43,6 +45,43 @@ struct PhaseTimer {
         t = now;
     }
 };
+
+// roctx ranges around the blocking ABI calls (SURVEY.md section 5 "tracing"): with ACX_ROCTX=1 every entry point that
+// enqueues device work pushes a range named after itself, so a `rocprofv3 --marker-trace --kernel-trace` timeline shows which
+// call each kernel belongs to.  Bound by dlopen on first use (librocprofiler-sdk-roctx / libroctx64); off by default: one
+// relaxed load per call.
+struct AbiRange {
+    using PushFn = int (*)(const char*);
+    using PopFn = int (*)();
+    static void bind(PushFn& push, PopFn& pop) {
+        static PushFn p_push = nullptr;
+        static PopFn p_pop = nullptr;
+        static std::once_flag once;
+        std::call_once(once, [] {
+            const char* e = std::getenv("ACX_ROCTX");
+            if (!e || std::atoi(e) == 0) return;
+            for (const char* nm : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+                if (void* so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) {
+                    p_push = reinterpret_cast<PushFn>(dlsym(so, "roctxRangePushA"));
+                    p_pop = reinterpret_cast<PopFn>(dlsym(so, "roctxRangePop"));
+                    if (p_push && p_pop) return;
+                    p_push = nullptr; p_pop = nullptr;
+                }
+            }
+        });
+        push = p_push; pop = p_pop;
+    }
+    PopFn pop = nullptr;
+    explicit AbiRange(const char* name) {
+        PushFn push = nullptr;
+        bind(push, pop);
+        if (push) push(name); else pop = nullptr;
+    }
+    ~AbiRange() { if (pop) pop(); }
+    AbiRange(const AbiRange&) = delete;
+    AbiRange& operator=(const AbiRange&) = delete;
+};
+#define ACX_RANGE() AbiRange acx_range_(__func__)
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -1572,6 +1611,7 @@ static void ensure_eval_plan(acx_r1cs* r) {
 }
 
 int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, acx_r1cs** out) {
+    ACX_RANGE();
     if (!ctx || !c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (c->field != ctx->field) return fail(ACX_ERR_INVALID_ARG, "circuit and context are over different fields");
     return guarded([&]() -> int { return circuit_to_r1cs_impl(ctx, c, roots, n_roots, out); });
@@ -1579,6 +1619,7 @@ int acx_circuit_to_r1cs(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots,
 
 int acx_circuit_to_r1cs_lists(acx_ctx* ctx, const acx_circuit* c, const acx_fr* roots, const uint32_t* counts, uint64_t n_lists,
                               uint32_t flags, acx_r1cs** out) {
+    ACX_RANGE();
     if (!ctx || !c || !out || (n_lists && !counts)) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (c->field != ctx->field) return fail(ACX_ERR_INVALID_ARG, "circuit and context are over different fields");
     if (flags & ~(uint32_t)ACX_ROOTS_REFERENCE_SEMANTICS) return fail(ACX_ERR_INVALID_ARG, "unknown flag");
@@ -1610,6 +1651,7 @@ int acx_circuit_to_r1cs_lists(acx_ctx* ctx, const acx_circuit* c, const acx_fr* 
 // ---------------------------------------------------------------------------------- R1CS
 int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C,
                   acx_r1cs** out) {
+    ACX_RANGE();
     const acx_csr* mats[3] = {A, B, C};
     return guarded([&]() -> int { return r1cs_from_host(ctx, n, m, mats, out); });
 }
@@ -1675,6 +1717,7 @@ static int verify_common(acx_r1cs* r, const acx_fr* witness, uint4* d_w, uint64_
 }
 
 int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
+    ACX_RANGE();
     if (!r || !witness || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
     LaneGuard lane(r->ctx);                                  // concurrent callers overlap: one stream + scratch per lane
     HIP_TRY(hipSetDevice(r->ctx->device));
@@ -1692,6 +1735,7 @@ int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad
 // crosses PCIe in ONE copy, is converted by one kernel, and the chunk is verified by ONE batched launch (blockIdx.y =
 // witness; the constraint stream of the system is shared by all of them and stays in L2 / Infinity Cache).
 int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad, uint64_t* first_bad) {
+    ACX_RANGE();
     if (!r || !ok || (count && !witnesses)) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (count == 0) return ACX_OK;
     return guarded([&]() -> int {
@@ -1743,6 +1787,7 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
 
 int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs, acx_fr* witness,
                   uint8_t* assigned) {
+    ACX_RANGE();
     if (!r || (n_inputs && !inputs)) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
     CtxLock lock(c->mu);
@@ -1796,6 +1841,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
 }
 
 int acx_r1cs_verify_resident(acx_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
+    ACX_RANGE();
     if (!r || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
     CtxLock lock(c->mu);
@@ -1815,6 +1861,7 @@ int acx_r1cs_verify_resident(acx_r1cs* r, int* ok, uint64_t* n_bad, uint64_t* fi
 }
 
 int acx_r1cs_residuals(acx_r1cs* r, const acx_fr* witness, acx_fr* out) {
+    ACX_RANGE();
     if (!r || !witness || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
     LaneGuard lane(c);
@@ -1915,6 +1962,7 @@ static int qap_h_dev_locked(acx_r1cs* r, const uint4* d_w, const H256* dl, uint4
 }
 
 int acx_qap_h_dev(acx_r1cs* r, const void* d_witness, const acx_fr* delta, void* d_h, uint64_t* d_result) {
+    ACX_RANGE();
     if (!r || !d_witness || !d_h || !d_result) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
     H256 dl[3];
@@ -1927,6 +1975,7 @@ int acx_qap_h_dev(acx_r1cs* r, const void* d_witness, const acx_fr* delta, void*
 }
 
 int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok) {
+    ACX_RANGE();
     if (!r || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_ctx* c = r->ctx;
     const HostField& hf = c->hf;
@@ -1957,6 +2006,7 @@ int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* o
 }
 
 int acx_qap_columns_dev(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, void* d_out, uint64_t* d_len) {
+    ACX_RANGE();
     if (!r || matrix < 0 || matrix > 2 || !d_out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
     if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
     acx_ctx* c = r->ctx;
@@ -1977,6 +2027,7 @@ int acx_qap_columns(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_
 // these per shard and bounds the sum)
 int qap_columns_host(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out, uint64_t* out_len,
                      uint64_t max_batch_bytes) {
+    AbiRange acx_range_("acx_qap_columns");
     if (!r || matrix < 0 || matrix > 2 || !out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
     if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
     if (wire_count == 0) return ACX_OK;
@@ -2082,6 +2133,7 @@ extern "C" {
 // ---------------------------------------------------------------------------------- NTT
 int acx_ntt(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift, const acx_fr* in,
             acx_fr* out) {
+    ACX_RANGE();
     if (!c || !in || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if ((int)log_n > c->hf.two_adicity()) return fail(ACX_ERR_TOO_LARGE, "log_n exceeds the field's two-adicity");
     LaneGuard lane(c);
@@ -2118,6 +2170,7 @@ int acx_dev_to_canonical(acx_ctx* c, uint64_t count, const void* d_in, void* d_o
 
 int acx_r1cs_verify_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset, uint64_t* d_result,
                         void* d_residuals, void* d_dots) {
+    ACX_RANGE();
     if (!r || !d_witness || !d_result) return fail(ACX_ERR_INVALID_ARG, "null argument");
     CtxLock lock(r->ctx->mu);
     HIP_TRY(hipSetDevice(r->ctx->device));
@@ -2149,6 +2202,7 @@ static int get_h_scale(acx_ctx* c, uint32_t log_n, const H256& g, const uint4** 
 
 int acx_r1cs_dots_h_dev(acx_r1cs* r, const void* d_witness, uint64_t row_offset, uint64_t* d_result, void* d_dots, uint32_t h_log_n,
                         const acx_fr* shift) {
+    ACX_RANGE();
     if (!r || !d_witness || !d_result || !d_dots) return fail(ACX_ERR_INVALID_ARG, "null argument");
     CtxLock lock(r->ctx->mu);
     HIP_TRY(hipSetDevice(r->ctx->device));
@@ -2204,6 +2258,7 @@ int acx_ntt_dist_step_ex_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_
 
 int acx_ntt_dist_step_fused_dev(acx_ctx* c, uint32_t log_n, uint32_t log_r, uint32_t world, uint32_t rank, int inverse, int step,
                                 uint32_t flags, const acx_fr* shift, const void* d_in, const void* d_mul, const void* d_add, void* d_out) {
+    ACX_RANGE();
     if (!c || !d_in || !d_out || (step != 0 && step != 1)) return fail(ACX_ERR_INVALID_ARG, "bad argument");
     if (d_mul && !inverse && step == 0 && shift) return fail(ACX_ERR_UNSUPPORTED, "no product on load of a forward coset step");
     if (d_add == d_out || d_mul == d_out) return fail(ACX_ERR_INVALID_ARG, "steps are out of place");
@@ -2241,6 +2296,7 @@ void acx_naive_destroy(acx_naive* nv) {
 }
 
 int acx_naive_create(acx_r1cs* r, const acx_fr* roots, uint64_t n_roots, acx_naive** out) {
+    ACX_RANGE();
     if (!r || !roots || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (n_roots != r->n) return fail(ACX_ERR_ROOT_COUNT, "one root per constraint row is required");
     if (r->n == 0 || r->n > 4096) return fail(ACX_ERR_TOO_LARGE, "naive interpolation supports 1..4096 rows");
@@ -2301,6 +2357,7 @@ int acx_naive_target(acx_naive* nv, acx_fr* out) {
 
 int acx_naive_columns(acx_naive* nv, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out,
                       uint64_t* out_len) {
+    ACX_RANGE();
     if (!nv || matrix < 0 || matrix > 2 || !out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
     acx_r1cs* r = nv->r;
     if (wire_begin + wire_count > r->m) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
@@ -2336,6 +2393,7 @@ int acx_naive_columns(acx_naive* nv, int matrix, uint64_t wire_begin, uint64_t w
 }
 
 int acx_naive_h(acx_naive* nv, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok) {
+    ACX_RANGE();
     if (!nv || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
     acx_r1cs* r = nv->r;
     acx_ctx* c = r->ctx;
@@ -2436,6 +2494,7 @@ void acx_batch_destroy(acx_batch* b) {
 }
 
 int acx_batch_verify_dev(acx_batch* b) {
+    ACX_RANGE();
     if (!b) return fail(ACX_ERR_INVALID_ARG, "null batch");
     acx_ctx* c = b->ctx;
     CtxLock lock(c->mu);
@@ -2453,6 +2512,7 @@ int acx_batch_verify_dev(acx_batch* b) {
 }
 
 int acx_ntt_dev(acx_ctx* c, uint32_t log_n, uint64_t batch, int inverse, const acx_fr* shift, void* d_data) {
+    ACX_RANGE();
     if (!c || !d_data) return fail(ACX_ERR_INVALID_ARG, "null argument");
     CtxLock lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));

@@ -1214,6 +1214,7 @@ int acx_mgpu_sync(acx_mgpu* mg) {
 
 int acx_mgpu_r1cs_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B, const acx_csr* C, uint32_t flags,
                        acx_mgpu_r1cs** out) {
+    ACX_RANGE();
     if (!mg || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     const acx_csr* mats[3] = {A, B, C};
     std::lock_guard<std::mutex> g(mg->mu);
@@ -1223,6 +1224,7 @@ int acx_mgpu_r1cs_load(acx_mgpu* mg, uint64_t n, uint64_t m, const acx_csr* A, c
 
 int acx_mgpu_circuit_to_r1cs(acx_mgpu* mg, const acx_circuit* c, const acx_fr* roots, uint64_t n_roots, uint32_t flags,
                              acx_mgpu_r1cs** out) {
+    ACX_RANGE();
     if (!mg || !c || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
     if (c->field != mg->field) return fail(ACX_ERR_INVALID_ARG, "circuit and context are over different fields");
     std::lock_guard<std::mutex> g(mg->mu);
@@ -1272,6 +1274,7 @@ int acx_mgpu_r1cs_dims(const acx_mgpu_r1cs* mr, uint64_t* n, uint64_t* m, uint32
 }
 
 int acx_mgpu_witness_upload(acx_mgpu_r1cs* mr, const acx_fr* witness) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || !witness) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "system is held whole on shard 0 (below the shard threshold): use the host-buffer calls");
@@ -1290,6 +1293,7 @@ int acx_mgpu_witness_upload(acx_mgpu_r1cs* mr, const acx_fr* witness) {
 }
 
 int acx_mgpu_r1cs_verify_resident(acx_mgpu_r1cs* mr, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
@@ -1307,6 +1311,7 @@ int acx_mgpu_r1cs_verify_resident(acx_mgpu_r1cs* mr, int* ok, uint64_t* n_bad, u
 }
 
 int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* mr, const acx_fr* witness, int* ok, uint64_t* n_bad, uint64_t* first_bad) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || !witness || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (!mr->sharded) return acx_r1cs_verify(mr->whole, witness, ok, n_bad, first_bad);
@@ -1328,6 +1333,7 @@ int acx_mgpu_r1cs_verify(acx_mgpu_r1cs* mr, const acx_fr* witness, int* ok, uint
 // Throughput form of the resident check: enqueue accumulates the violated-row count of ONE verification into ring slot
 // `slot` on every device and returns at once; verdicts reduces a range of slots with ONE collective and waits.
 int acx_mgpu_r1cs_verify_enqueue(acx_mgpu_r1cs* mr, uint32_t slot) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || slot >= kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot < 16)");
         if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
@@ -1347,6 +1353,7 @@ int acx_mgpu_r1cs_verify_enqueue(acx_mgpu_r1cs* mr, uint32_t slot) {
 }
 
 int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* mr, uint32_t slot0, uint32_t count, uint64_t* n_bad) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || !n_bad || count == 0 || slot0 + count > kMgRing) return fail(ACX_ERR_INVALID_ARG, "bad argument (slot0 + count <= 16)");
         if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "system is held whole on shard 0");
@@ -1402,6 +1409,7 @@ int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* mr, uint32_t slot0, uint32_t count, ui
 // witness k+1 crosses PCIe while witness k is being checked), its check accumulates into a ring slot, and the verdicts of up to
 // 16 witnesses are combined by ONE all-reduce.
 int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || !ok || (count && !witnesses)) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (count == 0) return ACX_OK;
@@ -1511,6 +1519,7 @@ int acx_mgpu_r1cs_verify_many(acx_mgpu_r1cs* mr, uint64_t count, const acx_fr* w
 }
 
 int acx_mgpu_qap_h_resident(acx_mgpu_r1cs* mr, const acx_fr* delta, int* ok) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "no resident witness (acx_mgpu_witness_upload) on a sharded system");
@@ -1544,6 +1553,7 @@ static int mg_qap_h_fetch_locked(acx_mgpu_r1cs* mr, acx_fr* out_h, uint64_t* h_l
 }
 
 int acx_mgpu_qap_h_fetch(acx_mgpu_r1cs* mr, acx_fr* out_h, uint64_t* h_len) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || !out_h || !h_len) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (!mr->sharded) return fail(ACX_ERR_UNSUPPORTED, "no h(x) on the devices (acx_mgpu_qap_h_resident)");
@@ -1554,6 +1564,7 @@ int acx_mgpu_qap_h_fetch(acx_mgpu_r1cs* mr, acx_fr* out_h, uint64_t* h_len) {
 }
 
 int acx_mgpu_qap_h(acx_mgpu_r1cs* mr, const acx_fr* witness, const acx_fr* delta, acx_fr* out_h, uint64_t* h_len, int* ok) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mr || !witness || !out_h || !h_len || !ok) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (!mr->sharded) return acx_qap_h(mr->whole, witness, delta, out_h, h_len, ok);
@@ -1586,6 +1597,7 @@ int acx_mgpu_qap_h(acx_mgpu_r1cs* mr, const acx_fr* witness, const acx_fr* delta
 }
 
 int acx_mgpu_qap_columns(acx_mgpu_r1cs* mr, int matrix, uint64_t wire_begin, uint64_t wire_count, acx_fr* out, uint64_t* out_len) {
+    ACX_RANGE();
     if (!mr || matrix < 0 || matrix > 2 || !out) return fail(ACX_ERR_INVALID_ARG, "bad argument");
     if (wire_begin > mr->m || wire_count > mr->m - wire_begin) return fail(ACX_ERR_INVALID_ARG, "wire range exceeds m");
     if (wire_count == 0) return ACX_OK;
@@ -1615,6 +1627,7 @@ int acx_mgpu_qap_columns(acx_mgpu_r1cs* mr, int matrix, uint64_t wire_begin, uin
 }
 
 int acx_mgpu_ntt(acx_mgpu* mg, uint32_t log_n, int inverse, const acx_fr* shift, const acx_fr* in, acx_fr* out) {
+    ACX_RANGE();
     return guarded([&]() -> int {
         if (!mg || !in || !out) return fail(ACX_ERR_INVALID_ARG, "null argument");
         if (!mg_can_distribute(mg->W, log_n)) return acx_ntt(mg->sh[0].ctx, log_n, 1, inverse, shift, in, out);

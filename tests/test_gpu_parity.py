@@ -1010,6 +1010,51 @@ def test_bench_ranks_on_one_device(world):
 
 
 @pytest.mark.gpu
+def test_roctx_ranges_around_abi_calls(tmp_path):
+    """with ACX_ROCTX=1 the blocking entry points push a roctx range named after themselves; a
+    `rocprofv3 --marker-trace` run of a small verification must show them (and the same program must run unchanged without
+    a profiler attached: the ranges are then no-ops)."""
+    _need_gpu()
+    import glob, os, shutil, sqlite3, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import importlib, sys\n"
+            f"sys.path.insert(0, {root!r})\n"
+            "acx = importlib.import_module('arithmetic-circuits_amd'); synth = acx.synth\n"
+            "ctx = acx.Context('bn254', 0); s = synth.mulgraph(1 << 12, n_in=64, window=256)\n"
+            "r = s.circuit.to_r1cs(ctx); w = s.witness()\n"
+            "assert r.verify(w)[0] and r.qap_h(w)[1]; print('ranges ok')\n")
+    env = dict(os.environ, ACX_ROCTX="1")
+    out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ranges ok" in out.stdout, out.stderr[-2000:]
+    if shutil.which("rocprofv3") is None:
+        return
+    d = str(tmp_path / "trace")
+    out = subprocess.run(["rocprofv3", "--marker-trace", "--kernel-trace", "-d", d, "-o", "t", "--", sys.executable, "-c", prog],
+                         env=dict(env, TMPDIR="/tmp"), cwd="/tmp", capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ranges ok" in out.stdout, out.stderr[-2000:]
+    names = set()
+    for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+        con = sqlite3.connect(db)
+        for (tbl,) in con.execute("select name from sqlite_master where type in ('table', 'view')").fetchall():
+            try:
+                cols = [c[1] for c in con.execute(f"pragma table_info('{tbl}')")]
+            except sqlite3.Error:
+                continue
+            for c in cols:
+                if c in ("name", "message", "string", "value"):
+                    try:
+                        names |= {str(x[0]) for x in con.execute(f"select distinct {c} from '{tbl}' where {c} like 'acx_%'")}
+                    except sqlite3.Error:
+                        pass
+    for f in glob.glob(os.path.join(d, "**", "*marker*"), recursive=True):
+        try:
+            names |= {w for w in open(f, errors="ignore").read().replace('"', " ").replace(",", " ").split() if w.startswith("acx_")}
+        except OSError:
+            pass
+    assert {"acx_circuit_to_r1cs", "acx_r1cs_verify", "acx_qap_h"} <= names, sorted(names)
+
+
+@pytest.mark.gpu
 def test_bench_line_survives_secondary_failures():
     """A secondary measurement that fails becomes an entry of "errors" and the line is still printed with its headline value
     (ACX_BENCH_FAIL injects the failure); a multi-rank run in which one rank never joins the distributed extras prints its
