@@ -224,32 +224,38 @@ def test_plain_c_host_drives_several_shards_without_rccl_or_hip_in_the_host(acx,
 
 def test_mgpu_configs3_2_24_constraints_through_rccl(acx, request):
     """BASELINE.json configs[3]'s constraint system -- 2^24 constraints = 256 block-diagonal 2^16-constraint mulgraph
-    systems, 4096 x 4096 four-step transforms -- through the N-GPU entry points on the one GPU of the box: one shard, the six
-    all-to-alls and the verdict all-reduce issued as real RCCL calls inside libacx.  h(x) -- all 2^24 coefficients -- and the
-    verdicts against the C oracle."""
+    systems, 4096 x 4096 four-step transforms -- through the N-GPU entry points on the one GPU of the box, twice: ONE shard
+    (the six all-to-alls and the verdict all-reduce issued as real RCCL calls inside libacx), and EIGHT shards on the one
+    device -- the 8-way split of the config itself: eight issuing threads, 2^21 block-cyclic rows per shard in runs of 512,
+    8 x 8 exchange blocks of 8 MiB per transform over peer copies, the witness replicated from shard 0.  h(x) -- all 2^24
+    coefficients -- and the verdicts against the C oracle, both times."""
     import os
     synth = acx.synth
-    mg = _mg(acx, request, "bn254", [0])
     orc = _orc(request, "bn254")
     bs = synth.BlockSystem(synth.mulgraph(1 << 16), 256)
     N = 1 << 24
     assert bs.n == N
     mats, w = bs.full_rows(), bs.witness()
-    mr = mg.load(bs.n, bs.m, *mats)
-    assert (mr.log_n, mr.n_shards) == (24, 1) and mg.transport == "rccl"
     threads = os.cpu_count() or 1
-    assert mr.verify(w) == (True, 0, U64_MAX)
-    h, ok = mr.qap_h(w)
     want_h, want_ok = orc.qap_h(bs.n, bs.m, 24, *mats, w, nthreads=threads)
-    assert ok and want_ok
-    assert np.array_equal(h, want_h[: h.shape[0]]) and not want_h[h.shape[0]:].any()
-    del want_h, h
+    assert want_ok
     bad = w.copy()
     bad[bs.wire(200, 77), 0] ^= np.uint64(1)
     _, nbad, first = orc.r1cs_residuals(bs.n, bs.m, *mats, bad, want_residuals=False, nthreads=threads)
-    assert nbad > 0 and mr.verify(bad) == (False, nbad, first)
-    assert mr.qap_h(bad) == (None, False)
-    mr.close()
+    assert nbad > 0
+    for devices, transport in (([0], "rccl"), ([0] * 8, "peer-copy")):
+        mg = _mg(acx, request, "bn254", devices)
+        mr = mg.load(bs.n, bs.m, *mats)
+        assert (mr.log_n, mr.n_shards) == (24, len(devices)) and mg.transport == transport
+        assert mr.verify(w) == (True, 0, U64_MAX)
+        h, ok = mr.qap_h(w)
+        assert ok
+        assert np.array_equal(h, want_h[: h.shape[0]]) and not want_h[h.shape[0]:].any()
+        del h
+        assert mr.verify(bad) == (False, nbad, first)
+        assert mr.qap_h(bad) == (None, False)
+        mr.close()
+        mg.close()
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0, 0, 0]], ids=lambda d: f"W{len(d)}")

@@ -72,9 +72,9 @@ def main():
             for key in sorted(c):
                 v = c[key]
                 if key == "FETCH_SIZE":
-                    parts.append(f"FETCH_SIZE={v / 1024:.1f}MB raw, x2={v / 512:.1f}MB")
+                    parts.append(f"FETCH_SIZE={v * 1024 / 1e6:.1f}MB raw, x2={v * 2048 / 1e6:.1f}MB")      # the counter is in KiB; MB = 10^6 bytes
                 elif key == "WRITE_SIZE":
-                    parts.append(f"WRITE_SIZE={v / 1024:.1f}MB")
+                    parts.append(f"WRITE_SIZE={v * 1024 / 1e6:.1f}MB")
                 else:
                     parts.append(f"{key}={v:.4g}")
             lines.append("    " + "  ".join(parts))
