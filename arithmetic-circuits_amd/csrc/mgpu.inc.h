@@ -500,7 +500,9 @@ int mg_upload_witness(acx_mgpu_r1cs* mr, const acx_fr* witness) {
             if (!mg->rccl) HIP_TRY(hipEventRecord(S.w_ready, S.ctx->stream));
         }
         if (mg->rccl)
-            NCCL_TRY(mg, mg->api->Broadcast(mr->part[0].d_w, d_w, mr->m * 4, ncclUint64, 0, S.comm, S.ctx->stream));
+            // in place on every rank: the root sends its own buffer, the others' send pointer is unused (and stays a pointer of
+            // THEIR device, whatever pointer checks the collective library applies)
+            NCCL_TRY(mg, mg->api->Broadcast(d_w, d_w, mr->m * 4, ncclUint64, 0, S.comm, S.ctx->stream));
         else {
             MG_BARRIER(mg);                                         // shard 0's w_ready is recorded
             if (s != 0) {
@@ -962,7 +964,7 @@ int mg_ensure_col_slices(acx_mgpu_r1cs* mr) {
 struct MgHArgs {
     const H256* dl;
     bool zk, fusedh;
-    H256 g, zinv, mzinv;
+    H256 g, ginv, zinv, mzinv;
 };
 
 int mg_qap_h_issue_shard(acx_mgpu_r1cs* mr, uint32_t s, const MgHArgs& A) {
@@ -980,12 +982,20 @@ int mg_qap_h_issue_shard(acx_mgpu_r1cs* mr, uint32_t s, const MgHArgs& A) {
     // Software pipeline over the three vectors (qap_h_dev_locked's sequence, sharded): vector k's exchange runs on the
     // exchange stream under vector k+1's local step, and a vector's coset transform starts as soon as its inverse one is
     // complete -- of the six all-to-alls only the last has no local work to hide behind.
-    for (int k = 0; k < 3; ++k) ACX_TRY(nt.begin(s, k, at(k), 1, nullptr, true));              // dots: ascending row order
+    // Without the zero-knowledge terms nobody needs the plain coefficients of L and R: their coset factor g^i rides on the
+    // closing multiplication of their INVERSE transform (an inverse coset transform with shift 1/g multiplies by g^i: +9 us on
+    // a step that otherwise closes with a plain reduction) instead of on the load of the forward one (-35 us: one product per
+    // element less), as in the single-GPU pipeline (qap_h_dev_locked).  O stays in plain coefficient form.
+    static const bool on_forward = [] { const char* e = std::getenv("ACX_MGPU_COSET_ON_FORWARD"); return e && std::atoi(e) != 0; }();   // development A/B: round 3's sequence
+    const bool fold = A.fusedh && !on_forward;
+    const H256* up = fold ? &A.ginv : nullptr;                      // shift of the inverse transforms of L and R
+    const H256* fw = fold ? nullptr : &A.g;                         // shift of their forward transforms
+    for (int k = 0; k < 3; ++k) ACX_TRY(nt.begin(s, k, at(k), 1, k < 2 ? up : nullptr, true));              // dots: ascending row order
     for (int k = 0; k < 3; ++k) {
-        ACX_TRY(nt.finish(s, k, at(3 + k), 1, nullptr));
-        if (k < 2) ACX_TRY(nt.begin(s, k, at(3 + k), 0, &A.g));
+        ACX_TRY(nt.finish(s, k, at(3 + k), 1, k < 2 ? up : nullptr));
+        if (k < 2) ACX_TRY(nt.begin(s, k, at(3 + k), 0, fw));
     }
-    for (int k = 0; k < 2; ++k) ACX_TRY(nt.finish(s, k, at(k), 0, &A.g));
+    for (int k = 0; k < 2; ++k) ACX_TRY(nt.finish(s, k, at(k), 0, fw));
     if (A.fusedh) {
         // without the zero-knowledge terms 1/z and -1/z ride on the stored dots, the last transform takes (L/z) * R as its first
         // step loads the points and adds -O/z behind its closing step (qap_h_dev_locked's fused form, sharded)
@@ -1042,6 +1052,7 @@ int mg_qap_h_resident(acx_mgpu_r1cs* mr, const H256* dl, bool* ok) {
     A.zk = dl && !(dl[0].is_zero() && dl[1].is_zero() && dl[2].is_zero());
     A.fusedh = !A.zk && mr->part[0].hscale != nullptr;
     A.g = hf.generator();
+    A.ginv = hf.inv(A.g);
     A.zinv = hf.inv(hf.sub(hf.pow_u64(A.g, N), hf.one()));
     A.mzinv = hf.sub(hf.zero(), A.zinv);
     ACX_TRY(mg_per_shard_threads(mg, [&](uint32_t s) -> int { return mg_qap_h_issue_shard(mr, s, A); }));

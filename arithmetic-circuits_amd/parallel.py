@@ -301,7 +301,10 @@ class ShardedR1CS:
 # ------------------------------------------------------------------------------------ distributed NTT
 class LocalOps:
     """Per-rank kernels the distributed pipeline is built from.  Tensors are int64 views of field
-    elements, shape (count, 4), in whatever element format the implementation uses."""
+    elements, shape (count, 4), in whatever element format the implementation uses.  `modulus`: the field's prime (the
+    pipeline inverts its coset generator)."""
+
+    modulus: int = 0
 
     def dist_step(self, src: torch.Tensor, dst: torch.Tensor, log_n: int, log_r: int, world: int, rank: int,
                   inverse: bool, step: int, shift: Optional[int], rows_t: bool = False,
@@ -326,6 +329,7 @@ class HipOps(LocalOps):
 
     def __init__(self, ctx: Context):
         self.ctx = ctx
+        self.modulus = ctx.p
         self._ext = torch.cuda.ExternalStream(ctx.stream)
 
     def _fenced(self, fn):
@@ -502,13 +506,17 @@ class DistributedQapH:
         # steps of vector k+1, and a vector's forward transform starts as soon as its inverse one is complete -- of
         # the six all-to-alls only the last one has no local work to hide behind.  Without an overlapping backend
         # (one rank, gloo) begin() completes the exchange itself and this is the plain sequence.
+        # Nobody needs the plain coefficients of L and R: their coset factor g^i rides on the closing multiplication of their
+        # INVERSE transform (an inverse coset transform with shift 1/g multiplies by g^i) instead of on the load of the forward
+        # one -- one product per element less on the steps that have it.  O stays in plain coefficient form.
+        ginv = pow(self.g, -1, self.ntt.ops.modulus)
         with nt.stream_context():
-            inv = [nt.begin(part(dots, k), True, None, slot=k, rows_t=self.sharded.rows_t) for k in range(3)]
+            inv = [nt.begin(part(dots, k), True, ginv if k < 2 else None, slot=k, rows_t=self.sharded.rows_t) for k in range(3)]
             fwd = []
             for k in range(3):
                 nt.finish(inv[k], out=part(tmp, k))
                 if k < 2:
-                    fwd.append(nt.begin(part(tmp, k), False, self.g, slot=k))
+                    fwd.append(nt.begin(part(tmp, k), False, None, slot=k))
             for k in range(2):
                 nt.finish(fwd[k], out=part(dots, k))
             # (L / z) * R on the way in, -O / z on the way out (O's coefficients are in COLS ownership, like h)

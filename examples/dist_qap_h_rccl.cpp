@@ -6,7 +6,8 @@
 //                 (rank*R/W + kl) + k2*R, so the residual kernel's <A_i,w>, <B_i,w>, <C_i,w> ARE three evaluation vectors in the
 //                 transposed ROWS layout, which the first inverse steps read through their strides (ACX_DIST_ROWS_T);
 //                 acx_r1cs_dots_h_dev stores them as <A_i,w> / z, <B_i,w>, -<C_i,w> / z (z = g^N - 1 on the coset)
-//   3 inverse     acx_ntt_dist_step_dev(step 0) -> ncclAllToAll -> (step 1): coefficients of L / z, R, -O / z in COLS ownership
+//   3 inverse     acx_ntt_dist_step_dev(step 0) -> ncclAllToAll -> (step 1): coefficients of L / z, R (each times g^i: their
+//                 inverse transforms are coset transforms with shift 1/g) and -O / z in COLS ownership
 //   2 coset       L / z and R only: O(x) enters the quotient in coefficient form
 //   1 inverse coset through acx_ntt_dist_step_fused_dev: its first step transforms the PRODUCT (L / z) * R as it loads the
 //                 points, its second step adds -O / z behind the closing multiplication: h in COLS ownership (rank g holds
@@ -113,6 +114,9 @@ int main() {
     uint64_t* d_res;
     HIPCHECK(hipMalloc((void**)&d_res, 16));
     acx_fr g = fr_u64(5);                                                    // coset generator: 5^N != 1 in BN254 Fr
+    // 1/5 mod r (little endian): an inverse coset transform with shift 1/g multiplies its result by g^i, which is how L and R
+    // receive their coset factor -- on the closing multiplication of their inverse transform, not on the load of the forward one
+    acx_fr ginv = {{0x67, 0x66, 0x66, 0xc6, 0xd4, 0xfb, 0xf3, 0xe7, 0x06, 0x2d, 0x4a, 0xca, 0xe9, 0x5c, 0xae, 0xa9, 0x8b, 0x56, 0xcd, 0x33, 0x7c, 0xb5, 0xb9, 0x49, 0xaa, 0xd9, 0x13, 0x5a, 0x94, 0x52, 0x5b, 0x13}};
     auto at = [&](void* base, uint64_t k) { return (void*)((char*)base + k * L * 32); };
     auto exchange = [&](void* s, void* r) -> int {
         if (world == 1) { HIPCHECK(hipMemcpyAsync(r, s, L * 32, hipMemcpyDeviceToDevice, stream)); return 0; }
@@ -136,8 +140,8 @@ int main() {
         const uint64_t init[2] = {0, ~0ull};
         HIPCHECK(hipMemcpyAsync(d_res, init, 16, hipMemcpyHostToDevice, stream));
         ACXCHECK(acx_r1cs_dots_h_dev(r_local, d_w, 0, d_res, dots, log_n, &g));            // dots: transposed ROWS layout, three vectors, 1/z and -1/z riding on them
-        for (uint64_t k = 0; k < 3; ++k) if (transform(1, nullptr, at(dots, k), at(coef, k), ACX_DIST_ROWS_T)) return 1;      // -> coefficients (COLS)
-        for (uint64_t k = 0; k < 2; ++k) if (transform(0, &g, at(coef, k), at(dots, k))) return 1;           // L, R on the coset (ROWS)
+        for (uint64_t k = 0; k < 3; ++k) if (transform(1, k < 2 ? &ginv : nullptr, at(dots, k), at(coef, k), ACX_DIST_ROWS_T)) return 1;      // -> coefficients (COLS): g^i L_i, g^i R_i, O_i
+        for (uint64_t k = 0; k < 2; ++k) if (transform(0, nullptr, at(coef, k), at(dots, k))) return 1;      // L, R on the coset (ROWS): plain transforms of the shifted coefficients
         // the last transform: (L / z) * R on the way in, -O / z on the way out -> h (COLS)
         ACXCHECK(acx_ntt_dist_step_fused_dev(ctx, log_n, log_r, world, rank, 1, 0, 0, &g, at(dots, 0), at(dots, 1), nullptr, send));
         if (exchange(send, recv)) return 1;

@@ -34,6 +34,7 @@ class OracleOps(par.LocalOps):
 
     def __init__(self, orc):
         self.orc = orc
+        self.modulus = orc.p
 
     def _ntt(self, vals, log_len, inverse):
         return limbs_to_ints(self.orc.ntt(ints_to_limbs(vals), log_len, inverse=inverse))

@@ -5,7 +5,9 @@ four-step transform take (world, rank) as plain arguments, the rank's block-cycl
 row source, and the all-to-all moves a known number of bytes.  Prints microseconds per local step (HIP events on
 libacx's stream) and the exchange volume, from which the 8-GPU time of one distributed h(x) follows:
 
-    t = residual_dots_h + 3 * (inv0t + inv1) + 2 * (fwd0c + fwd1) + (inv0m + inv1ca) + 6 * exchange + all-reduce
+    t = residual_dots_h + 3 * inv0t + 2 * inv1c + inv1 + 2 * (fwd0 + fwd1) + (inv0m + inv1ca) + 6 * exchange + all-reduce
+(round 4: the coset factor g^i of L and R rides on the closing multiplication of their INVERSE transforms -- inv1c instead of inv1 --
+so their forward transforms are plain, fwd0 instead of fwd0c; round 3's sequence, 3 * (inv0t + inv1) + 2 * (fwd0c + fwd1), is printed beside it.)
 (six transforms: O(x) stays in coefficient form; the rank's rows are loaded in ascending order, so the three
 inverse transforms of the dots start from the transposed ROWS block: inv0t; 1/z and -1/z ride on the stored dots, the last
 transform takes the product L * R on the way in (inv0m) and adds -O/z on the way out (inv1ca): no elementwise pass is left.
@@ -81,7 +83,8 @@ def main():
     t["sub_o"] = timed(stream, lambda: ctx.qap_sub_o_dev(y.data_ptr(), dots[2 * L:].data_ptr(), L, ln, g))
     xbytes = L * 32 * (W - 1) // W
     local_r2 = t["residual_dots"] + 3 * (t["inv0t"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["pointwise"] + t["inv0"] + t["inv1c"] + t["sub_o"]
-    local = t["residual_dots_h"] + 3 * (t["inv0t"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["inv0m"] + t["inv1ca"]
+    local_r3 = t["residual_dots_h"] + 3 * (t["inv0t"] + t["inv1"]) + 2 * (t["fwd0c"] + t["fwd1"]) + t["inv0m"] + t["inv1ca"]
+    local = t["residual_dots_h"] + 3 * t["inv0t"] + 2 * t["inv1c"] + t["inv1"] + 2 * (t["fwd0"] + t["fwd1"]) + t["inv0m"] + t["inv1ca"]
     print(f"rank-local budget of a {W}-rank job, N = 2^{ln} = 2^{lr} x 2^{ln - lr}, {a.field} Fr, {L} elements per rank (us):")
     for k, v in t.items():
         print(f"  {k:14s} {v:10.1f}")
@@ -90,7 +93,7 @@ def main():
         ex = xbytes / (7 * bw) * 1e6 if W > 1 else 0.0
         print(f"  h(x) per rank: local {local:9.1f} us + 6 exchanges at {bw / 1e9:.0f} GB/s/link x 7 links {6 * ex:8.1f} us = {local + 6 * ex:9.1f} us"
               f" -> {(1 << ln) / (local + 6 * ex) * 1e6:.3e} constraints/s over {W} GPUs")
-    print(f"  (round 2's sequence with the two elementwise kernels: local {local_r2:9.1f} us)")
+    print(f"  (round 3's sequence, coset factor on the forward transforms' load: local {local_r3:9.1f} us; round 2's, with the two elementwise kernels: {local_r2:9.1f} us)")
     dnt = t["fwd0"] + t["fwd1"]
     print(f"  one forward transform per rank: {dnt:.1f} us local (+ exchange)")
 
