@@ -2070,10 +2070,12 @@ int qap_columns_host(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t wire
 // Scratch of the host-buffer entry points (lane arenas, transform ping-pong buffers) back to the device: what a caller that
 // keeps many contexts on one device (the N-GPU handle with a repeated ordinal) does after a call with large outputs.
 void ctx_trim_scratch(acx_ctx* c) {
-    CtxLock lock(c->mu);
     (void)hipSetDevice(c->device);
     for (auto& ln : c->lanes) {
-        std::lock_guard<std::mutex> g(ln.mu);
+        // a lane in use keeps its scratch (and the lane mutex is the ONLY lock taken here: a call on a lane takes ctx->mu while
+        // holding its lane, so taking them in the other order could deadlock against it)
+        std::unique_lock<std::mutex> g(ln.mu, std::try_to_lock);
+        if (!g.owns_lock()) continue;
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
         if (ln.copy_stream) (void)hipStreamSynchronize(ln.copy_stream);
         if (ln.arena) { (void)hipFree(ln.arena); ln.arena = nullptr; ln.arena_bytes = 0; }

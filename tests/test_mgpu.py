@@ -339,6 +339,22 @@ def test_mgpu_qap_columns_shared_out_by_wire(acx, request, field, devices):
         mr.qap_columns(3, 0, 1)
 
 
+@pytest.mark.parametrize("mode", ["copies", "pinned"])
+def test_mgpu_witness_replication_modes(mode):
+    """ACX_MGPU_WITNESS selects how the witness reaches the shards: the default is one host-to-device copy + a device-side
+    broadcast; `copies` (one pageable copy per shard) and `pinned` (the same from memory the library page-locks for the call)
+    must give the same results -- the verify / h(x) equality test of this file, run in a child process under each mode."""
+    import os, subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_mgpu.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+           "-k", "verify_and_h_equal_single_gpu_and_oracle and bn254"]
+    out = subprocess.run(cmd, cwd=root, env=dict(os.environ, ACX_MGPU_WITNESS=mode), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and " passed" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
 def test_mgpu_qap_columns_device_memory_is_one_system_not_W(acx, request):
     """Eight shards on one device: what acx_mgpu_qap_columns leaves on the device for its column views must stay below 1.5x
     ONE system (every entry is held once, 40 bytes, by the shard that owns its wire) -- the first version gave each of the
