@@ -1355,20 +1355,20 @@ int qap_columns_core(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t cnt,
     const uint64_t N = 1ull << r->log_n;
     const DevMatrix& T = r->T[matrix];
     if (cnt == 0) return ACX_OK;
-    // Columns of at most kDirectMax entries (nearly every wire of a gate-list circuit) are interpolated directly
-    // (k_col_direct: k products per coefficient); the others -- inputs used by many gates, the constant wire -- form
+    // Columns of at most kDirectMid entries (nearly every wire of a gate-list circuit) are interpolated directly
+    // (k_col_direct up to 4 entries, k_col_direct_mid for 5 .. 8: k products per coefficient); the others -- inputs used by many gates, the constant wire -- form
     // runs that take the batched inverse transform.  Many short runs: the whole batch takes the transform.
     static const bool direct_ok = [] { const char* e = getenv("ACX_COLUMNS_DIRECT"); return !e || atoi(e) != 0; }();
     std::vector<std::pair<uint64_t, uint64_t>> runs;      // dense runs [begin, end) inside the batch
-    uint64_t n_sparse = 0;
+    uint64_t n_sparse = 0, n_mid = 0;
     if (direct_ok && T.h_ptr.size() > wire_begin + cnt) {
         const uint32_t* hp = T.h_ptr.data() + wire_begin;
         for (uint64_t i = 0; i < cnt; ++i) {
-            if (hp[i + 1] - hp[i] <= kDirectMax) { ++n_sparse; continue; }
+            if (hp[i + 1] - hp[i] <= kDirectMid) { ++n_sparse; n_mid += hp[i + 1] - hp[i] > kDirectMax; continue; }
             if (!runs.empty() && runs.back().second == i) runs.back().second = i + 1; else runs.emplace_back(i, i + 1);
         }
     }
-    if (n_sparse == 0 || runs.size() > 16) { runs.assign(1, {0, cnt}); n_sparse = 0; }
+    if (n_sparse == 0 || runs.size() > 16) { runs.assign(1, {0, cnt}); n_sparse = 0; n_mid = 0; }
     for (const auto& run : runs)
         HIP_TRY(hipMemsetAsync(d_out + 2 * run.first * N, 0, (run.second - run.first) * N * 32, cur_stream(c)));
     if (T.nnz && !runs.empty())       // entries of sparse columns land in memory the direct kernel overwrites afterwards
@@ -1391,6 +1391,8 @@ int qap_columns_core(acx_r1cs* r, int matrix, uint64_t wire_begin, uint64_t cnt,
             const uint64_t nb = std::min<uint64_t>(32768, cnt - b);
             P.wire_begin = wire_begin + b;
             DISPATCH_FIELD(c, hipLaunchKernelGGL((k_col_direct<F>), dim3(gx, (unsigned)nb), dim3(kBlock), 0, cur_stream(c), P, d_out + 2 * b * N));
+            if (n_mid)      // columns of 5 .. 8 entries in the batch: the same grid once more, every other block leaves at once
+                DISPATCH_FIELD(c, hipLaunchKernelGGL((k_col_direct_mid<F>), dim3(gx, (unsigned)nb), dim3(kBlock), 0, cur_stream(c), P, d_out + 2 * b * N));
         }
     }
     if (d_len) DISPATCH_FIELD(c, hipLaunchKernelGGL((k_poly_len<F>), dim3((unsigned)cnt), dim3(kBlock), 0, cur_stream(c), (const uint4*)d_out, r->log_n, d_len, (const u32*)T.ptr + wire_begin));

@@ -1059,7 +1059,9 @@ __global__ __launch_bounds__(kBlock) void k_scatter_columns(const u32* __restric
 // Columns with more than kDirectMax entries keep the batched inverse NTT (the host splits a batch into dense runs and the
 // rest).  blockIdx.y = column of the batch; a block produces kBlock * L consecutive coefficients (every store of the block is
 // one contiguous 8 KiB run).
-constexpr u32 kDirectMax = 4;
+constexpr u32 kDirectMax = 4;       // k_col_direct: one shared reduction per coefficient
+constexpr u32 kDirectMid = 12;      // k_col_direct_mid: 5 .. 12 entries, a reduction per group of four (a kernel of its own: its
+                                    // lane factors would cost the common case its fifth wave)
 struct ColDirect {
     const u32* colptr;
     const u32* rowidx;
@@ -1085,6 +1087,7 @@ __device__ __forceinline__ void col_direct_entry(const ColDirect& P, u32 e, u32 
     row = sload(P.rowidx + e);
     const Fe v = fe_mul<F>(fe_sload(P.val + 2 * (u64)e), inv_n);
     lane = fe_mul<F>(omega_inv_pow<F>(P, ((u64)row * l) & mask), v);
+    __builtin_amdgcn_sched_barrier(0);      // entry by entry: the set-up of eight entries scheduled together peaks at 183 registers
 }
 // (a fold over the entries, not a loop: three products per entry are more than `#pragma unroll` will unroll, and a rolled
 // loop would index lane[] dynamically, i.e. keep it in scratch memory)
@@ -1111,6 +1114,62 @@ __device__ __forceinline__ void col_direct_body(const ColDirect& P, uint4* __res
 #pragma unroll
         for (int t = 0; t < K; ++t) b[t] = fe_sload(P.tw_blk + 2 * (((u64)row[t] * (blk + s)) & bmask));
         fe_store(dst + 2 * (u64)s * kBlock, fe_dot<F, K>(lane, b));
+    }
+}
+
+// 5 .. kDirectMid entries: the same factorisation, the entries in groups of four with a reduction each (a column accumulator
+// holds six terms), 81 k + 90 ceil(k / 4) multiplier instructions per coefficient -- against ten 171-instruction products per
+// coefficient for the transform such a column took before (tools/kbench.py colsk: 33 - 56 us per 2^20-point column for
+// k = 5 .. 12 against 107).  The lane factors alone are 9 k registers: 2 waves per SIMD, which this rare class can afford.
+template <class F, int G>
+__device__ __forceinline__ Fe col_direct_group(const ColDirect& P, const Fe (&lane)[G], const u32 (&row)[G], u64 x, u64 bmask) {
+    Fe b[G];
+#pragma unroll
+    for (int t = 0; t < G; ++t) b[t] = fe_sload(P.tw_blk + 2 * (((u64)row[t] * x) & bmask));
+    const Fe r = fe_dot<F, G>(lane, b);
+    // one group after the other, a group's step factors loaded behind the previous group's products: all of them at once are
+    // more scalar registers of limbs than the scalar file leaves
+    __builtin_amdgcn_sched_barrier(0);
+    return r;
+}
+
+template <class F, int K>
+__device__ __forceinline__ void col_direct_mid_body(const ColDirect& P, uint4* __restrict__ out, u32 e0) {
+    constexpr int K2 = K > 8 ? 4 : K - 4, K3 = K > 8 ? K - 8 : 0;
+    const u64 N = 1ull << P.log_n, mask = N - 1;
+    const u32 l = threadIdx.x;
+    if (l >= N) return;
+    const u64 blk = (u64)blockIdx.x * P.steps;
+    uint4* dst = out + 2 * (((u64)blockIdx.y << P.log_n) + blk * kBlock + l);
+    const u64 bmask = (N >> 8) ? (N >> 8) - 1 : 0;
+    Fe la[4], lb[K2], lc[K3 ? K3 : 1];
+    u32 ra[4], rb[K2], rc[K3 ? K3 : 1];
+    const Fe inv_n = fe_from_arg(P.inv_n);
+    col_direct_setup<F>(P, e0, l, mask, inv_n, la, ra, std::make_integer_sequence<int, 4>{});
+    col_direct_setup<F>(P, e0 + 4, l, mask, inv_n, lb, rb, std::make_integer_sequence<int, K2>{});
+    if constexpr (K3 > 0) col_direct_setup<F>(P, e0 + 8, l, mask, inv_n, lc, rc, std::make_integer_sequence<int, K3>{});
+#pragma unroll 1
+    for (u32 s = 0; s < P.steps; ++s) {
+        Fe sum = fe_add<F>(col_direct_group<F, 4>(P, la, ra, blk + s, bmask), col_direct_group<F, K2>(P, lb, rb, blk + s, bmask));
+        if constexpr (K3 > 0) sum = fe_add<F>(sum, col_direct_group<F, (K3 ? K3 : 1)>(P, lc, rc, blk + s, bmask));
+        fe_store(dst + 2 * (u64)s * kBlock, sum);
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_col_direct_mid(ColDirect P, uint4* __restrict__ out) {
+    const u64 wire = P.wire_begin + blockIdx.y;
+    const u32 e0 = sload(P.colptr + wire), k = sload(P.colptr + wire + 1) - e0;       // uniform over the block
+    switch (k) {
+        case 5: col_direct_mid_body<F, 5>(P, out, e0); break;
+        case 6: col_direct_mid_body<F, 6>(P, out, e0); break;
+        case 7: col_direct_mid_body<F, 7>(P, out, e0); break;
+        case 8: col_direct_mid_body<F, 8>(P, out, e0); break;
+        case 9: col_direct_mid_body<F, 9>(P, out, e0); break;
+        case 10: col_direct_mid_body<F, 10>(P, out, e0); break;
+        case 11: col_direct_mid_body<F, 11>(P, out, e0); break;
+        case 12: col_direct_mid_body<F, 12>(P, out, e0); break;
+        default: break;                                           // k_col_direct's or the transform's
     }
 }
 

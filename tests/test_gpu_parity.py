@@ -1330,9 +1330,9 @@ def test_qap_columns_device_variant_and_batches(request, acx):
 @pytest.mark.parametrize("field,n,pattern", [("bn254", 5, "mixed"), ("bn254", 200, "alternate"), ("bn254", 1024, "mixed"),
                                              ("bls12_381", 3000, "mixed"), ("bn254", 5000, "alternate"), ("bls12_381", 40000, "blocks")])
 def test_qap_columns_sparse_direct_and_dense_runs(request, acx, field, n, pattern):
-    """createPolynomialsFFT column by column on matrices whose columns hold 0 .. 9 entries: columns of at most four
-    entries are interpolated directly (k_col_direct, sums of geometric progressions), the others through the batched
-    inverse NTT; "mixed" = a few dense runs inside the batch, "alternate" = more runs than the run limit (the whole
+    """createPolynomialsFFT column by column on matrices whose columns hold 0 .. 17 entries: columns of at most four
+    entries are interpolated directly (k_col_direct, sums of geometric progressions), those of 5 .. 12 by k_col_direct_mid
+    (groups of four entries, a reduction each), the others through the batched inverse NTT; "mixed" = a few dense runs inside the batch, "alternate" = more runs than the run limit (the whole
     batch takes the transform), "blocks" = long sparse and dense stretches.  Every coefficient against the C oracle,
     host and device variants, stripped lengths, N from 2^3 to 2^16."""
     import torch
@@ -1340,12 +1340,12 @@ def test_qap_columns_sparse_direct_and_dense_runs(request, acx, field, n, patter
     rs = np.random.RandomState(n)
     m = 60
     if pattern == "alternate":
-        counts = [(7 if c % 2 else c % 5) for c in range(m)]
+        counts = [(14 if c % 2 else c % 9) for c in range(m)]
     elif pattern == "blocks":
-        counts = [(c % 5) if (c // 15) % 2 == 0 else 5 + c % 5 for c in range(m)]
+        counts = [(c % 13) if (c // 15) % 2 == 0 else 13 + c % 5 for c in range(m)]
     else:
-        counts = [int(x) for x in rs.choice([0, 1, 1, 2, 3, 4, 4, 5, 9], size=m)]
-        counts[10:14] = [6, 7, 8, 9]
+        counts = [int(x) for x in rs.choice([0, 1, 1, 2, 3, 4, 4, 5, 9, 12, 13], size=m)]
+        counts[10:20] = [6, 7, 8, 9, 10, 11, 12, 13, 15, 5]
     counts = [min(k, n) for k in counts]
     per_row = [[] for _ in range(n)]
     for c, k in enumerate(counts):

@@ -132,6 +132,45 @@ def bench_cols(ctx, stream, log_n, wires=64):
           f"{total * n * 32 / dt / 1e9:.1f} GB/s of coefficients to the host")
 
 
+def bench_cols_by_entries(ctx, stream, log_n, wires=64, kmax=14):
+    """createPolynomialsFFT of columns with EXACTLY k entries, k = 0 .. kmax (a synthetic A matrix: column w of block k holds k
+    random entries on random rows): what a column costs by its entry count -- k_col_direct (k <= 4), k_col_direct_mid (5 .. 8),
+    scatter + batched inverse transform beyond.  Every block is checked against the C oracle on its first column."""
+    from oracle.c_oracle import COracle
+    orc = COracle("bn254")
+    n, m = 1 << log_n, 1 + (kmax + 1) * wires
+    rng = np.random.RandomState(7)
+    rows, cols = [], []
+    for k in range(kmax + 1):
+        for w in range(wires):
+            rr = rng.choice(n, size=k, replace=False)
+            rows.append(rr)
+            cols.append(np.full(k, 1 + k * wires + w))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    rowptr = np.zeros(n + 1, dtype=np.uint32)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.uint32)
+    A = (rowptr, cols.astype(np.uint32), synth.random_fr(cols.shape[0], 11, 1))
+    empty = (np.zeros(n + 1, dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.zeros((0, 4), dtype=np.uint64))
+    r = acx.R1CS.load(ctx, n, m, A, empty, empty)
+    out = torch.empty((wires * n, 4), dtype=torch.int64, device="cuda")
+    lens = torch.zeros(wires, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for k in range(kmax + 1):
+        w0 = 1 + k * wires
+        r.qap_columns_dev(0, w0, wires, out.data_ptr(), lens.data_ptr())
+        ctx.sync()
+        got = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        ctx.dev_to_canonical(n, out.data_ptr(), got.data_ptr())
+        ctx.sync()
+        want = orc.qap_columns(n, log_n, A, w0, 1, nthreads=16)[0]
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), want), f"k = {k}: column differs from the oracle's"
+        us = time_stream(stream, lambda: r.qap_columns_dev(0, w0, wires, out.data_ptr(), lens.data_ptr()), 5)
+        print(f"qap_columns_dev N=2^{log_n}, {wires} columns of exactly {k:2d} entries: {us / wires:7.1f} us per column ({32 * n / (us / wires) * 1e-6:6.2f} TB/s of coefficients)")
+
+
 N_IN, WINDOW, COEFF = 1024, 4096, "random"
 
 
@@ -158,6 +197,8 @@ def main():
             bench_ntt(ctx, stream, ln, a.reps, batch=64 if ln <= 20 else 8)
         if a.what == "cols":
             bench_cols(ctx, stream, ln)
+        if a.what == "colsk":
+            bench_cols_by_entries(ctx, stream, ln)
         if a.what == "h":
             bench_h(ctx, ln)
 
