@@ -1617,6 +1617,8 @@ int acx_mgpu_qap_columns(acx_mgpu_r1cs* mr, int matrix, uint64_t wire_begin, uin
         acx_mgpu* mg = mr->mg;
         std::lock_guard<std::mutex> g(mg->mu);
         DevGuard dg;
+        // one shard: its slab IS the whole system, and the single-GPU call builds the column view from it on the device
+        if (mg->W == 1) return acx_qap_columns(mr->part[0].slab, matrix, wire_begin, wire_count, out, out_len);
         ACX_TRY(mg_ensure_col_slices(mr));
         // every shard interpolates the blocks of the range it owns, straight into the caller's buffers: no exchange at all.
         // Device-side batches are bounded so that all shards together stage at most 2 x 256 MiB of coefficients (at least one
