@@ -164,6 +164,78 @@ def mulgraph(n: int, n_in: int = 1024, k: int = 2, window: int = 4096, seed: int
     return SynthCircuit(circ, inputs, n, n_in, k)
 
 
+def gatemix(n_gates: int, n_in: int = 64, seed: int = 0x6A7E, field: str = "bn254", weights=(50, 10, 1), split_bits: int = 256,
+            window: int = 4096) -> SynthCircuit:
+    """`n_gates` gates in the reference's own generator mix (test/Test/Circuit/Arithmetic.hs:69-136: Mul : Equal : Split =
+    50 : 10 : 1, Split always 256 bits wide): a Mul gate multiplies two affine sides s1 * Var(x1) + s2 * Var(x2), x an input or
+    one of the last `window` intermediate wires; an Equal or Split gate reads an earlier intermediate wire.  Every gate writes
+    fresh IntermediateWires (Mul 1, Equal 2: magic and output, Split `split_bits`), so the list is in single-assignment form and
+    Split rows (257 entries) take the long-row path.  Counter-based randomness like mulgraph; flat arrays, no per-gate objects."""
+    g = np.arange(n_gates, dtype=np.uint64)
+    pick = _stream(seed, 1, g) % np.uint64(sum(weights))
+    kind = np.where(pick < weights[0], 0, np.where(pick < weights[0] + weights[1], 1, 2)).astype(np.uint8)
+    kind[0] = 0                                              # the first gate has no intermediate wire to read
+    new = np.where(kind == 0, 1, np.where(kind == 1, 2, split_bits)).astype(np.int64)
+    first = np.concatenate([[0], np.cumsum(new)])[:-1]       # first intermediate wire a gate writes = wires before it
+    # an Equal gate's magic wire is written but is not one of its `outputWires` (src/Circuit/Arithmetic.hs:158-185): a read
+    # that lands on one moves to the gate's output wire next to it, so that validArithCircuit holds
+    magic = np.zeros(int(first[-1] + new[-1]) + 1, dtype=np.uint32)
+    magic[first[kind == 1]] = 1
+    mul = np.nonzero(kind == 0)[0]
+    nm = mul.shape[0]
+    # Mul gates: two sides x two terms
+    t = np.arange(4 * nm, dtype=np.uint64)
+    gate_of_t = np.repeat(mul, 4)
+    before = first[gate_of_t].astype(np.uint64)
+    use_mid = ((_stream(seed, 2, t) & np.uint64(1)) == 1) & (before > 0)
+    r = _stream(seed, 3, t)
+    span = np.maximum(np.minimum(before, np.uint64(window)), np.uint64(1))
+    aff = np.zeros((4 * nm, 2), dtype=np.uint32)
+    aff[:, 0] = use_mid.astype(np.uint32)
+    mid = (before - np.uint64(1) - (r % span)).astype(np.int64)
+    mid = np.where(use_mid, mid, 0)
+    aff[:, 1] = np.where(use_mid, mid + magic[mid], r % np.uint64(n_in)).astype(np.uint32)
+    scalars = random_fr(4 * nm, seed, 10, field)
+    # tokens per Mul side: ADD, SMUL, VAR, SMUL, VAR
+    tok_per_gate = np.where(kind == 0, 10, 0).astype(np.int64)
+    side = np.zeros(2 * n_gates + 1, dtype=np.int64)
+    side[1::2] = np.where(kind == 0, 5, 0)
+    side[2::2] = np.where(kind == 0, 5, 0)
+    tok_ofs = np.concatenate([[0], np.cumsum(side[1:])]).astype(np.uint64)
+    n_tok = int(tok_ofs[-1])
+    tok_op = np.tile(np.array([0, 1, 3, 1, 3], dtype=np.uint8), 2 * nm)
+    tok_arg = np.zeros(n_tok, dtype=np.uint32)
+    term = np.arange(4 * nm, dtype=np.uint32)                # side-major: term 2 * side + {0, 1}
+    base = (np.arange(2 * nm, dtype=np.int64) * 5)
+    for j in (0, 1):
+        tok_arg[base + 1 + 2 * j] = term[j::2]
+        tok_arg[base + 2 + 2 * j] = term[j::2]
+    assert tok_op.shape[0] == n_tok
+    # wires per gate: Mul {out}; Equal {input, magic, out}; Split {input, bits...}
+    nw = np.where(kind == 0, 1, np.where(kind == 1, 3, 1 + split_bits)).astype(np.int64)
+    wire_ofs = np.concatenate([[0], np.cumsum(nw)]).astype(np.uint64)
+    wires = np.zeros((int(wire_ofs[-1]), 2), dtype=np.uint32)
+    wires[:, 0] = 1
+    pos = wire_ofs[:-1].astype(np.int64)
+    rin = _stream(seed, 4, g)
+    src = (first.astype(np.uint64) - np.uint64(1) - (rin % np.maximum(np.minimum(first.astype(np.uint64), np.uint64(window)), np.uint64(1)))).astype(np.uint32)
+    src = src + magic[np.where(first > 0, src, 0)]
+    wires[pos[kind == 0], 1] = first[kind == 0]
+    eq = kind == 1
+    wires[pos[eq], 1] = src[eq]
+    wires[pos[eq] + 1, 1] = first[eq]
+    wires[pos[eq] + 2, 1] = first[eq] + 1
+    sp = np.nonzero(kind == 2)[0]
+    if sp.shape[0]:
+        wires[pos[sp], 1] = src[sp]
+        bits = (pos[sp] + 1).reshape(-1, 1) + np.arange(split_bits).reshape(1, -1)
+        wires[bits.reshape(-1), 1] = (first[sp].reshape(-1, 1) + np.arange(split_bits).reshape(1, -1)).reshape(-1)
+    gl = _lib.GateList(n_gates, kind.ctypes.data, tok_ofs.ctypes.data, tok_op.ctypes.data, tok_arg.ctypes.data,
+                       scalars.ctypes.data, scalars.shape[0], aff.ctypes.data, aff.shape[0], wire_ofs.ctypes.data, wires.ctypes.data)
+    circ = Circuit(field, gl, (kind, tok_ofs, tok_op, tok_arg, scalars, aff, wire_ofs, wires))
+    return SynthCircuit(circ, random_fr(n_in, seed, 12, field), n_gates, n_in, 2)
+
+
 class BlockSystem:
     """`blocks` block-diagonal copies of one mulgraph system that share only the constant wire: the shape of
     BASELINE.json configs[3] (2^24 constraints = 256 x 2^16) without ever materialising it on one host.  Any

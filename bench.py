@@ -12,7 +12,8 @@ asynchronously on a double-buffered ring of result slots.
 
 Beside the headline, rank 0 measures one parity-gated object per config of BASELINE.json -- `reference_bench` (configs[0]: the
 reference's own four criterion benchmarks of bench/Circuit.hs:26-36 through the C ABI), `ntt` / `qap_h` / `load` / `qap_columns`
-(configs[2]), `e2e` (the host-buffer boundary, PCIe included), `bls12_381` (configs[4]), `r1cs_small_coeff`, `cpu_baseline` --
+(configs[2]), `e2e` (the host-buffer boundary, PCIe included), `bls12_381` (configs[4]), `r1cs_small_coeff`, `gate_mix` (the
+reference's own generator shape: Equal / Split gates, 257-entry rows), `cpu_baseline` --
 each under guard(): a failure becomes an entry of "errors", the line is always printed.  --only / --skip select them.
 
 Prints ONE JSON line on rank 0."""
@@ -709,6 +710,45 @@ def run_with_deadline(fn, seconds, device):
     return box.get("r"), box.get("e")
 
 
+def bench_gate_mix(ctx, field="bn254", n_gates=60000):
+    """The reference's OWN circuit shape (test/Test/Circuit/Arithmetic.hs:69-136: Mul : Equal : Split = 50 : 10 : 1, 256-bit Split) at
+    60 000 gates: `generateAssignment` on the GPU (level-parallel: Equal gates invert, Split gates extract bits) beside the host fold,
+    and `verifyAssignment` with ~1000 rows of 257 entries on the long-row path.  Parity: the GPU witness equals the host fold's and
+    satisfies the ORACLE's check; residual vector, violated-row count and first row under a corrupted witness equal the oracle's."""
+    from oracle.c_oracle import COracle
+    orc = COracle(field)
+    s = synth.gatemix(n_gates, field=field)
+    c = s.circuit
+    mats = s.rows()
+    r = c.to_r1cs(ctx)
+
+    def wall(fn, reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    w_host, _ = c.eval(s.inputs)
+    gw, _ = r.eval_witness(s.inputs)
+    _, nbad, _ = orc.r1cs_residuals(r.n, r.m, *mats, gw, want_residuals=False, nthreads=effective_cpus())
+    wb = gw.copy()
+    wb[1 + c.n_inputs + 7, 0] ^= np.uint64(1)            # an early intermediate wire (a magic wire behind a zero input would go unnoticed)
+    want_res, want_bad, want_first = orc.r1cs_residuals(r.n, r.m, *mats, wb, nthreads=effective_cpus())
+    assert want_bad > 0
+    parity = bool(np.array_equal(gw, w_host) and nbad == 0 and r.verify(gw)[0] and np.array_equal(r.residuals(wb), want_res)
+                  and r.verify(wb) == (False, want_bad, want_first))
+    fmt = r.format()
+    t_verify = wall(lambda: r.verify_resident(), 20)
+    return {"workload": f"{n_gates} gates in the reference's generator mix (Mul : Equal : Split = 50 : 10 : 1, 256-bit Split; {field} Fr): "
+                        f"{r.n} constraints, m = {r.m} wires, {fmt[2]} rows on the long-row path",
+            "parity_vs_oracle": parity,
+            "generateAssignment": {"gpu_acx_r1cs_eval_s": wall(lambda: r.eval_witness(s.inputs, download=False), 5),
+                                   "host_acx_circuit_eval_s": wall(lambda: c.eval(s.inputs), 3)},
+            "verifyAssignment": {"resident_s": t_verify, "constraints_per_s": r.n / t_verify,
+                                 "host_buffer_s": wall(lambda: r.verify(gw), 20)}}
+
+
 def bench_distributed(ctx, a, world, rank, dist):
     """configs[3] beside the headline (N > 1, or --force-dist on one GPU): the distributed four-step NTT at
     N = 2^24 (one all-to-all per transform) and the distributed h(x) pipeline on a 2^24-constraint block system
@@ -930,7 +970,7 @@ def main():
     ap.add_argument("--only-steps", action="store_true", help="internal: nothing but the batched launches (the child of the PMC pass)")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--only-ntt", action="store_true", help="internal: nothing but 40 single 2^20-point transforms (the child of the NTT counter pass)")
-    ap.add_argument("--skip", default="", help="comma list of secondary objects to skip: pmc,ntt,qap_h,small,ref,load,cols,e2e,field2,cpu,dist or all")
+    ap.add_argument("--skip", default="", help="comma list of secondary objects to skip: pmc,ntt,qap_h,small,ref,gatemix,load,cols,e2e,field2,cpu,dist or all")
     ap.add_argument("--only", default="", help="comma list of secondary objects to run (the rest is skipped)")
     ap.add_argument("--dist-deadline", type=float, default=240.0, help="seconds the distributed extras of a multi-rank run may take before the line is printed without them")
     ap.add_argument("--launcher", default="auto", choices=["auto", "ranks", "mgpu"],
@@ -1274,6 +1314,8 @@ def secondary_objects(a, out, ctx, stream, world, use_dist, device, systems, wit
         put("r1cs_small_coeff", "small", bench_small_coeff, ctx, stream, a.field, copies=a.copies, log_n=a.logn, prewarm=a.prewarm)
     if single and a.want("ref"):
         put("reference_bench", "ref", reference_bench, ctx, a.field)
+    if single and a.want("gatemix"):
+        put("gate_mix", "gatemix", bench_gate_mix, ctx, a.field)
     c3 = None
     if need_c3:
         c3 = guard("c3_load", lambda: c3_f.result().load(ctx))

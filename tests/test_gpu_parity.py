@@ -1101,6 +1101,7 @@ def test_bench_single_gpu_line_objects():
         assert d["e2e"][k]["constraints_per_s"] > 0
     b = d["bls12_381"]
     assert b["r1cs_verify"]["parity_vs_oracle"] and b["ntt"]["parity_vs_oracle"] and b["qap_h"]["parity_vs_oracle"]
+    assert d["gate_mix"]["parity_vs_oracle"] and d["gate_mix"]["verifyAssignment"]["constraints_per_s"] > 0
 
 
 @pytest.mark.gpu

@@ -131,6 +131,28 @@ def test_degenerate_root_lists_follow_the_reference(acx, fname, mode, seed):
     assert e.value.status == acx._lib.STATUS["ROOT_COUNT"]
 
 
+@pytest.mark.parametrize("fname", ["bn254", "bls12_381"])
+def test_gatemix_generator_is_valid_and_satisfiable(acx, fname):
+    """synth.gatemix (the reference's generator mix 50 : 10 : 1 with 256-bit Split gates, flat arrays): `validArithCircuit`
+    holds, the host fold's witness satisfies every row under the C oracle, Split gates put 257-entry rows into A, the same seed
+    gives the same bytes, and a flipped witness bit is caught."""
+    from oracle.c_oracle import COracle
+    orc = COracle(fname)
+    s = acx.synth.gatemix(3000, n_in=16, seed=11, field=fname)
+    c = s.circuit
+    kinds = np.bincount(c._keep[0], minlength=3)
+    assert c.valid() and kinds[0] > 4 * kinds[1] > 0 and kinds[2] > 0
+    assert c.n_rows == kinds[0] + 2 * kinds[1] + 257 * kinds[2]
+    mats, w = s.rows(), s.witness()
+    assert int(np.diff(mats[0][0]).max()) == 256       # 2^j on every bit wire (the input wire carries an explicit 0)
+    _, nbad, _ = orc.r1cs_residuals(c.n_rows, c.m, *mats, w, want_residuals=False)
+    assert nbad == 0
+    w2 = acx.synth.gatemix(3000, n_in=16, seed=11, field=fname).witness()
+    assert np.array_equal(w, w2)
+    w[1 + c.n_inputs, 0] ^= np.uint64(1)              # the first Mul gate's output wire: its own row must fail
+    assert orc.r1cs_residuals(c.n_rows, c.m, *mats, w, want_residuals=False)[1] > 0
+
+
 def test_eval_undefined_wire_is_an_error_code(acx):
     """src/Circuit/Arithmetic.hs:128,137 panic -> ACX_ERR_UNDEFINED_WIRE."""
     for gate in (acx.Equal(acx.IntermediateWire(5), acx.IntermediateWire(0), acx.OutputWire(0)),
