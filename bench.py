@@ -610,6 +610,12 @@ def bench_e2e(r, w, c3=None, many=48):
         w2 = c3.w.copy()
         with Pinned(w2):
             big["verify_pinned"] = {"constraints_per_s": rate(c3.r.n, lambda: one(c3.r, w2), 10)}
+
+        def hx():
+            h, ok = c3.r.qap_h(c3.w)
+            assert ok and h.shape[0] > 0, "host-buffer h(x) rejected a satisfying witness"
+        # verificationWitness through host buffers: witness in, the quotient's N coefficients out (acx_qap_h)
+        big["qap_h_host_buffers"] = {"constraints_per_s": rate(c3.r.n, hx, 3)}
         out["configs2"] = big
     out["note"] = "PCIe-inclusive wall clock per blocking C-ABI call (H2D + conversion + launch + verdict D2H); the device-resident launch is the headline"
     return out
