@@ -4,6 +4,9 @@
 // marshalling code, tests/test_host_sanitized.py).
 #pragma once
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -22,6 +25,18 @@ static int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+
+// ACX_TRACE_LOAD=1: wall-clock of the phases of acx_r1cs_load / acx_circuit_to_r1cs on stderr (development aid)
+struct PhaseTimer {
+    bool on = std::getenv("ACX_TRACE_LOAD") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[acx load] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 // Nothing may propagate through the C ABI: host allocations sized by caller data can throw.
 template <class Fn>

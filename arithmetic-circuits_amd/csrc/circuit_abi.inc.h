@@ -32,9 +32,12 @@ int acx_circuit_create(int field, const acx_gate_list* gates, acx_circuit** out)
         c->field = field;
         c->hc.hf = field == ACX_FIELD_BN254_FR ? HostField::make<Bn254Fr>() : HostField::make<Bls12381Fr>();
         std::string msg;
+        PhaseTimer pt;
         const int rc = c->hc.init(gates, msg);
         if (rc != ACX_OK) return fail(rc, msg);
+        pt.mark("circuit: copy + validate");
         c->hc.build_rows(c->rows[0], c->rows[1], c->rows[2]);
+        pt.mark("circuit: gateToGenQAP rows");
         *out = c.release();
         return ACX_OK;
     });

@@ -92,7 +92,8 @@ struct HostCsr {
     std::vector<uint32_t> rowptr{0};
     std::vector<uint32_t> col;
     std::vector<H256> val;  // canonical
-    void push_row(const HostField& hf, const std::map<uint64_t, H256>& row) {
+    template <class Row>     // any range of (column, Montgomery value) pairs in ascending column order
+    void push_row(const HostField& hf, const Row& row) {
         for (const auto& kv : row) {
             if (kv.second.is_zero()) continue;  // explicit zeros of the reference are numerically void
             col.push_back((uint32_t)kv.first);
@@ -206,42 +207,54 @@ public:
         return ACX_OK;
     }
 
-    // affineCircuitToAffineMap of the sub-tree whose pre-order tokens are [begin, end).  Iterative: the tokens
-    // are consumed right to left with an explicit value stack (a prefix expression read backwards is a postfix
-    // one), so a 10^5-term left-nested Add chain -- the natural foldl shape -- costs heap, not call stack.
-    // Add = Map.unionWith (+) (smaller map merged into the larger), ScalarMul scales constant and entries.
-    void affine_map(uint64_t begin, uint64_t end, H256& cst, std::map<uint64_t, H256>& vec) const {
-        struct Val { H256 cst; std::map<uint64_t, H256> vec; };
-        std::vector<Val> st;
-        for (uint64_t pos = end; pos-- > begin;) {
+    // One row of one matrix: (column, value) pairs, ascending and unique by column once finished.  A flat vector, not a
+    // std::map: a gate's row holds a handful of entries and is built 3 * 2^20 times for a 2^20-gate circuit.
+    using Entries = std::vector<std::pair<uint64_t, H256>>;
+    static void set_entry(Entries& row, uint64_t col, const H256& v) {       // Map.insert: a later value for the same wire overwrites
+        for (auto& kv : row) if (kv.first == col) { kv.second = v; return; }
+        row.emplace_back(col, v);
+    }
+    static void sort_entries(Entries& row) {
+        std::sort(row.begin(), row.end(), [](const std::pair<uint64_t, H256>& x, const std::pair<uint64_t, H256>& y) { return x.first < y.first; });
+    }
+
+    // affineCircuitToAffineMap of the sub-tree whose pre-order tokens are [begin, end) (src/Circuit/Affine.hs:90-105), in ONE
+    // left-to-right pass with a stack of pending scale factors instead of a map per node: a node is reached with the product s
+    // of the ScalarMul factors above it; Add hands s to both sub-trees, ScalarMul c hands s c to its sub-tree, ConstGate c adds
+    // s c to the constant, Var x emits the term (x, s).  Scaling distributes over Map.unionWith (+) exactly in a field, so the
+    // terms of one wire, summed at the end, are the reference's map entry -- including the wire whose coefficients cancel, which
+    // stays with value 0.  No recursion and no allocation per node: a 10^5-term Add chain costs one stack of scales.
+    // `vec` comes back ascending and unique by column.
+    void affine_map(uint64_t begin, uint64_t end, H256& cst, Entries& vec) const {
+        static thread_local std::vector<H256> st;
+        st.clear();
+        st.push_back(hf.one());
+        vec.clear();
+        cst = hf.zero();
+        const H256 one = hf.one();
+        for (uint64_t pos = begin; pos < end; ++pos) {
+            const H256 sc = st.back();
+            st.pop_back();
             const uint8_t op = tok_op[pos];
             const uint32_t arg = tok_arg[pos];
-            if (op == ACX_AFF_VAR) {
-                st.emplace_back();
-                st.back().cst = hf.zero();
-                st.back().vec[flat(aff_wires[arg])] = hf.one();
-            } else if (op == ACX_AFF_CONST) {
-                st.emplace_back();
-                st.back().cst = scalars[arg];
-            } else if (op == ACX_AFF_SCALARMUL) {
-                Val& v = st.back();
-                v.cst = hf.mul(scalars[arg], v.cst);
-                for (auto& kv : v.vec) kv.second = hf.mul(scalars[arg], kv.second);
-            } else {  // ADD: left operand is on top (it was read last)
-                Val l = std::move(st.back());
-                st.pop_back();
-                Val& r = st.back();
-                r.cst = hf.add(l.cst, r.cst);
-                if (l.vec.size() > r.vec.size()) std::swap(l.vec, r.vec);
-                for (const auto& kv : l.vec) {
-                    auto it = r.vec.find(kv.first);
-                    if (it == r.vec.end()) r.vec.emplace(kv.first, kv.second);
-                    else it->second = hf.add(it->second, kv.second);
+            if (op == ACX_AFF_VAR) vec.emplace_back(flat(aff_wires[arg]), sc);
+            else if (op == ACX_AFF_CONST) cst = hf.add(cst, sc == one ? scalars[arg] : hf.mul(sc, scalars[arg]));
+            else if (op == ACX_AFF_SCALARMUL) st.push_back(sc == one ? scalars[arg] : hf.mul(sc, scalars[arg]));
+            else { st.push_back(sc); st.push_back(sc); }
+        }
+        if (vec.size() > 1) {
+            bool sorted = true;
+            for (size_t i = 1; i < vec.size() && sorted; ++i) sorted = vec[i - 1].first < vec[i].first;
+            if (!sorted) {
+                sort_entries(vec);
+                size_t w = 0;
+                for (size_t i = 1; i < vec.size(); ++i) {
+                    if (vec[i].first == vec[w].first) vec[w].second = hf.add(vec[w].second, vec[i].second);
+                    else vec[++w] = vec[i];
                 }
+                vec.resize(w + 1);
             }
         }
-        cst = st.back().cst;
-        vec = std::move(st.back().vec);
     }
 
     // evalAffineCircuit of the tokens [begin, end): failed lookups are 0.  Same right-to-left evaluation.
@@ -297,63 +310,69 @@ public:
         });
     }
 
-    // gateToGenQAP of ONE gate (src/QAP.hs:366-474): its rows as {A, B, C} maps column -> value holding EVERY wire the
+    // gateToGenQAP of ONE gate (src/QAP.hs:366-474): its rows as {A, B, C} entry lists (column, value) holding EVERY wire the
     // reference's row mentions -- the constant, the updated wires, explicit zeros included.  The zeros are void while roots are
     // distinct (push_row drops them); they decide what survives when two rows share a root (build_rows_reference).
-    using RowMaps = std::array<std::map<uint64_t, H256>, 3>;
-    void gate_rows(uint64_t g, std::vector<RowMaps>& rows) const {
+    using RowMaps = std::array<Entries, 3>;
+    // returns the gate's row count; rows[0 .. count) are filled (the vector only grows: its inner buffers are reused gate after gate)
+    size_t gate_rows(uint64_t g, std::vector<RowMaps>& rows) const {
         const H256 one = hf.one(), minus_one = hf.neg(hf.one()), zero = hf.zero();
         const acx_wire* gw = &wires[wire_ofs[g]];
-        rows.clear();
+        const size_t count = rows_of_gate(g);
+        if (rows.size() < count) rows.resize(count);
+        for (size_t i = 0; i < count; ++i) for (auto& e : rows[i]) e.clear();
         if (kind[g] == ACX_GATE_MUL) {
-            rows.emplace_back();
             auto& l = rows[0][0]; auto& r = rows[0][1]; auto& o = rows[0][2];
             H256 lc, rc;
             affine_map(tok_ofs[2 * g], tok_ofs[2 * g + 1], lc, l);
             affine_map(tok_ofs[2 * g + 1], tok_ofs[2 * g + 2], rc, r);
-            l[0] = lc;  // constantQapSet (root, leftInputConst): a Var can never name column 0
-            r[0] = rc;
-            o[0] = zero;
-            o[flat(gw[0])] = one;
+            // constantQapSet (root, leftInputConst): a Var can never name column 0, so the constant goes in front
+            l.insert(l.begin(), {0, lc});
+            r.insert(r.begin(), {0, rc});
+            o.emplace_back(0, zero);
+            o.emplace_back(flat(gw[0]), one);
         } else if (kind[g] == ACX_GATE_EQUAL) {
             const uint64_t i = flat(gw[0]), mg = flat(gw[1]), out = flat(gw[2]);
             auto set3 = [&](H256 vi, H256 vm, H256 vo, H256 cst) {
-                std::map<uint64_t, H256> row;
-                row[0] = cst;
-                row[i] = vi; row[mg] = vm; row[out] = vo;  // updateAtWires: later entries overwrite
+                Entries row;
+                row.emplace_back(0, cst);
+                set_entry(row, i, vi); set_entry(row, mg, vm); set_entry(row, out, vo);  // updateAtWires: later entries overwrite
+                sort_entries(row);
                 return row;
             };
-            rows.resize(2);
             rows[0] = {set3(one, zero, zero, zero), set3(zero, one, zero, zero), set3(zero, zero, one, zero)};      // row0: i * m = out
             rows[1] = {set3(zero, zero, minus_one, one), set3(one, zero, zero, zero), set3(zero, zero, zero, zero)}; // row1: (1 - out) * i = 0
         } else {
             const uint64_t n_outs = wire_ofs[g + 1] - wire_ofs[g] - 1;
             const uint64_t inp = flat(gw[0]);
-            rows.resize(1 + n_outs);
             auto& a0 = rows[0][0]; auto& b0 = rows[0][1]; auto& c0 = rows[0][2];
-            a0[0] = zero; a0[inp] = zero;
+            // updateAtWires ((inp, 0) : zip outputs 2^j) over the constant: a later pair for the same wire overwrites.  A std::map
+            // here (one per Split gate): the overwrite needs a lookup and a row has 257 entries.
+            std::map<uint64_t, H256> a0m;
+            a0m[0] = zero; a0m[inp] = zero;
             H256 pw = one;  // 2^j
             for (uint64_t j = 0; j < n_outs; ++j) {
-                a0[flat(gw[1 + j])] = pw;
+                a0m[flat(gw[1 + j])] = pw;
                 pw = hf.add(pw, pw);
             }
-            b0[0] = one; b0[inp] = zero;
-            c0[0] = zero; c0[inp] = one;
+            a0.assign(a0m.begin(), a0m.end());
+            b0 = {{0, one}, {inp, zero}};
+            c0 = {{0, zero}, {inp, one}};
             for (uint64_t j = 0; j < n_outs; ++j) {  // bit * (1 - bit) = 0
                 const uint64_t o = flat(gw[1 + j]);
-                auto& a = rows[1 + j][0]; auto& b = rows[1 + j][1]; auto& c = rows[1 + j][2];
-                a[0] = zero; a[o] = one;
-                b[0] = one; b[o] = minus_one;
-                c[0] = zero; c[o] = zero;
+                rows[1 + j][0] = {{0, zero}, {o, one}};
+                rows[1 + j][1] = {{0, one}, {o, minus_one}};
+                rows[1 + j][2] = {{0, zero}, {o, zero}};
             }
         }
+        return count;
     }
 
     void build_rows_range(uint64_t g_begin, uint64_t g_end, HostCsr& A, HostCsr& B, HostCsr& C) const {
         std::vector<RowMaps> rows;
         for (uint64_t g = g_begin; g < g_end; ++g) {
-            gate_rows(g, rows);
-            for (const auto& r : rows) { A.push_row(hf, r[0]); B.push_row(hf, r[1]); C.push_row(hf, r[2]); }
+            const size_t count = gate_rows(g, rows);
+            for (size_t i = 0; i < count; ++i) { A.push_row(hf, rows[i][0]); B.push_row(hf, rows[i][1]); C.push_row(hf, rows[i][2]); }
         }
     }
 
@@ -390,11 +409,11 @@ public:
         std::vector<RowMaps> rows;
         uint64_t pos = 0;
         for (uint64_t g = 0; g < used; ++g) {
-            gate_rows(g, rows);
-            for (const auto& r : rows) {
+            const size_t count = gate_rows(g, rows);
+            for (size_t i = 0; i < count; ++i) {
                 const uint64_t ri = (uint64_t)(std::lower_bound(distinct.begin(), distinct.end(), rv[pos++], less) - distinct.begin());
                 for (int k = 0; k < 3; ++k)
-                    for (const auto& kv : r[k]) merged[k][ri][kv.first] = kv.second;       // Map.fromList: the later pair wins
+                    for (const auto& kv : rows[i][k]) merged[k][ri][kv.first] = kv.second;       // Map.fromList: the later pair wins
             }
         }
         for (int k = 0; k < 3; ++k) {

@@ -34,17 +34,6 @@ using namespace acx;
 
 #include "abi_common.inc.h"
 
-// ACX_TRACE_LOAD=1: wall-clock of the phases of acx_r1cs_load / acx_circuit_to_r1cs on stderr (development aid)
-struct PhaseTimer {
-    bool on = std::getenv("ACX_TRACE_LOAD") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void mark(const char* what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[acx load] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-        t = now;
-    }
-};
 
 // roctx ranges around the blocking ABI calls (SURVEY.md section 5 "tracing"): with ACX_ROCTX=1 every entry point that
 // enqueues device work pushes a range named after itself, so a `rocprofv3 --marker-trace --kernel-trace` timeline shows which
