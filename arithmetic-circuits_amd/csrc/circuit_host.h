@@ -88,10 +88,35 @@ inline void parallel_ranges(uint64_t n, unsigned T, Body&& body) {
     if (err) std::rethrow_exception(err);
 }
 
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the big arrays of a circuit (hundreds
+// of MB at 2^20 gates) are filled by worker threads right after being sized, and value-initialising them first means ONE
+// thread touching every page -- a quarter of acx_circuit_create at 8 threads (ACX_TRACE_LOAD).
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U, class... Args>
+    void construct(U* p, Args&&... args) {
+        if constexpr (sizeof...(Args) == 0) ::new ((void*)p) U;            // default-initialisation: nothing for trivial types
+        else ::new ((void*)p) U(std::forward<Args>(args)...);
+    }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
+
+// dst = src[0 .. n) copied (and first touched) by the worker threads
+template <class T>
+inline void parallel_copy(RawVec<T>& dst, const T* src, uint64_t n) {
+    dst.resize(n);
+    parallel_ranges(n, host_threads(n * sizeof(T), 4u << 20), [&](unsigned, uint64_t b, uint64_t e) {
+        if (e > b) std::memcpy(dst.data() + b, src + b, (e - b) * sizeof(T));
+    });
+}
+
 struct HostCsr {
     std::vector<uint32_t> rowptr{0};
-    std::vector<uint32_t> col;
-    std::vector<H256> val;  // canonical
+    RawVec<uint32_t> col;
+    RawVec<H256> val;  // canonical
     template <class Row>     // any range of (column, Montgomery value) pairs in ascending column order
     void push_row(const HostField& hf, const Row& row) {
         for (const auto& kv : row) {
@@ -107,14 +132,14 @@ class HostCircuit {
 public:
     HostField hf;
     uint64_t n_gates = 0;
-    std::vector<uint8_t> kind;
-    std::vector<uint64_t> tok_ofs;
-    std::vector<uint8_t> tok_op;
-    std::vector<uint32_t> tok_arg;
-    std::vector<H256> scalars;  // Montgomery
-    std::vector<acx_wire> aff_wires;
-    std::vector<uint64_t> wire_ofs;
-    std::vector<acx_wire> wires;
+    RawVec<uint8_t> kind;
+    RawVec<uint64_t> tok_ofs;
+    RawVec<uint8_t> tok_op;
+    RawVec<uint32_t> tok_arg;
+    RawVec<H256> scalars;  // Montgomery
+    RawVec<acx_wire> aff_wires;
+    RawVec<uint64_t> wire_ofs;
+    RawVec<acx_wire> wires;
     uint64_t n_in = 0, n_mid = 0, n_out = 0;
 
     uint64_t m() const { return 1 + n_in + n_mid + n_out; }
@@ -146,9 +171,9 @@ public:
         if (n_gates == 0) {                       // the empty circuit: the caller may pass NULL arrays
             kind.clear(); tok_ofs = {0}; wire_ofs = {0};
         } else {
-            kind.assign(gl->kind, gl->kind + n_gates);
-            tok_ofs.assign(gl->tok_ofs, gl->tok_ofs + 2 * n_gates + 1);
-            wire_ofs.assign(gl->wire_ofs, gl->wire_ofs + n_gates + 1);
+            parallel_copy(kind, gl->kind, n_gates);
+            parallel_copy(tok_ofs, gl->tok_ofs, 2 * n_gates + 1);
+            parallel_copy(wire_ofs, gl->wire_ofs, n_gates + 1);
         }
         const uint64_t n_tok = tok_ofs.back(), n_w = wire_ofs.back();
         if ((n_tok && (!gl->tok_op || !gl->tok_arg)) || (n_w && !gl->wires) || (gl->n_aff_wires && !gl->aff_wires) ||
@@ -157,9 +182,9 @@ public:
             if (tok_ofs[i] > tok_ofs[i + 1]) { msg = "tok_ofs not monotone"; return ACX_ERR_BAD_CIRCUIT; }
         for (size_t i = 0; i + 1 < wire_ofs.size(); ++i)
             if (wire_ofs[i] > wire_ofs[i + 1]) { msg = "wire_ofs not monotone"; return ACX_ERR_BAD_CIRCUIT; }
-        if (n_tok) { tok_op.assign(gl->tok_op, gl->tok_op + n_tok); tok_arg.assign(gl->tok_arg, gl->tok_arg + n_tok); }
-        if (n_w) wires.assign(gl->wires, gl->wires + n_w);
-        if (gl->n_aff_wires) aff_wires.assign(gl->aff_wires, gl->aff_wires + gl->n_aff_wires);
+        if (n_tok) { parallel_copy(tok_op, gl->tok_op, n_tok); parallel_copy(tok_arg, gl->tok_arg, n_tok); }
+        if (n_w) parallel_copy(wires, gl->wires, n_w);
+        if (gl->n_aff_wires) parallel_copy(aff_wires, gl->aff_wires, gl->n_aff_wires);
         scalars.resize(gl->n_scalars);
         {
             std::atomic<bool> noncanonical{false};
