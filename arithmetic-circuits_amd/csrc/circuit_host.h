@@ -502,10 +502,17 @@ public:
         std::vector<uint32_t> level_ofs;   // [n_levels + 1] into items
         std::vector<uint32_t> items;       // gate ids, grouped by level
         std::vector<uint8_t> written;      // [m] wire is assigned by some gate (or is the constant)
+        // Equal gates in gate order, when NO gate reads an Equal gate's magic wire (validArithCircuit never lets one: the magic
+        // wire is not among outputWires, src/Circuit/Arithmetic.hs:158-185): the inversions then hang off the dependency graph
+        // as leaves and are evaluated in one launch after the last level instead of adding their latency to every level.
+        std::vector<uint32_t> deferred_equal;
+        bool defer_magic = false;
     };
     bool build_plan(EvalPlan& plan) const {
         const uint64_t M = m();
         std::vector<int64_t> writer(M, -1);
+        std::vector<uint8_t> is_magic(M, 0);
+        bool magic_is_read = false;
         for (uint64_t g = 0; g < n_gates; ++g) {
             const acx_wire* gw = &wires[wire_ofs[g]];
             const uint64_t nw = wire_ofs[g + 1] - wire_ofs[g];
@@ -517,7 +524,8 @@ public:
             };
             if (kind[g] == ACX_GATE_MUL) { if (!claim(gw[0])) return false; }
             else if (kind[g] == ACX_GATE_EQUAL) { if (gw[1].kind == gw[2].kind && gw[1].index == gw[2].index) return false;
-                                                   if (!claim(gw[1]) || !claim(gw[2])) return false; }
+                                                   if (!claim(gw[1]) || !claim(gw[2])) return false;
+                                                   is_magic[flat(gw[1])] = 1; }
             else for (uint64_t j = 1; j < nw; ++j) if (!claim(gw[j])) return false;
         }
         std::vector<uint32_t> level(n_gates, 0);
@@ -531,6 +539,7 @@ public:
                 const int64_t wr = writer[flat(w)];
                 if (wr < 0) return;                        // never written: reads as absent
                 if ((uint64_t)wr >= g) { ok = false; return; }   // written later: order-dependent
+                if (is_magic[flat(w)]) magic_is_read = true;
                 lv = std::max(lv, level[wr] + 1);
             };
             if (kind[g] == ACX_GATE_MUL) {
@@ -550,6 +559,10 @@ public:
         plan.written.assign(M, 0);
         plan.written[0] = 1;
         for (uint64_t k = 0; k < M; ++k) if (writer[k] >= 0) plan.written[k] = 1;
+        plan.defer_magic = !magic_is_read;
+        plan.deferred_equal.clear();
+        if (plan.defer_magic)
+            for (uint64_t g = 0; g < n_gates; ++g) if (kind[g] == ACX_GATE_EQUAL) plan.deferred_equal.push_back((uint32_t)g);
         return true;
     }
 

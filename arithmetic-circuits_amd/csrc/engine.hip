@@ -232,6 +232,9 @@ struct acx_r1cs {
     uint8_t* ev_kind = nullptr;
     uint4* ev_mul = nullptr;             // per plan item: the Mul gate's record (k_eval_level)
     u32* ev_cols = nullptr;              // per plan item: kEvalLanes columns (k_eval_level_lanes)
+    u32* ev_equal = nullptr;             // Equal gates whose magic wires k_eval_magic fills after the last level (n_ev_equal of them)
+    uint32_t n_ev_equal = 0;
+    bool ev_defer_magic = false;
     bool has_csc = false;
     uint4* d_w = nullptr;  // the witness acx_r1cs_eval leaves resident (m elements); acx_naive_h uses it as scratch
     bool resident_valid = false;                     // d_w holds a witness produced by acx_r1cs_eval
@@ -1179,6 +1182,7 @@ void free_r1cs_device(acx_r1cs* r) {
     if (r->long_rows) (void)hipFree(r->long_rows);
     if (r->ev_mul) { (void)hipFree(r->ev_mul); r->ev_mul = nullptr; }
     if (r->ev_cols) { (void)hipFree(r->ev_cols); r->ev_cols = nullptr; }
+    if (r->ev_equal) { (void)hipFree(r->ev_equal); r->ev_equal = nullptr; }
     if (r->ev_items) (void)hipFree(r->ev_items);
     if (r->ev_row) (void)hipFree(r->ev_row);
     if (r->ev_wire_ofs) (void)hipFree(r->ev_wire_ofs);
@@ -1581,6 +1585,7 @@ static void ensure_eval_plan(acx_r1cs* r) {
         if (up((void**)&r->ev_items, plan.items.data(), plan.items.size() * 4) && up((void**)&r->ev_row, row.data(), row.size() * 4) &&
             up((void**)&r->ev_wire_ofs, wofs.data(), wofs.size() * 4) && up((void**)&r->ev_wires, wflat.data(), wflat.size() * 4) &&
             up((void**)&r->ev_kind, hc.kind.data(), hc.kind.size()) && up((void**)&r->ev_mul, mul.data(), mul.size() * 4) &&
+            up((void**)&r->ev_equal, plan.deferred_equal.data(), plan.deferred_equal.size() * 4) &&
             hipMalloc((void**)&r->ev_cols, plan.items.size() * kEvalLanes * 4 + 4) == hipSuccess) {
             // level-ordered copy of the first four columns of each recorded Mul gate's A and B rows (k_eval_level_lanes)
             const uint64_t lanes = (uint64_t)plan.items.size() * kEvalLanes;
@@ -1590,6 +1595,8 @@ static void ensure_eval_plan(acx_r1cs* r) {
                 if (hipStreamSynchronize(cur_stream(ctx)) != hipSuccess) return;
             }
             r->has_plan = true;
+            r->ev_defer_magic = plan.defer_magic;
+            r->n_ev_equal = (uint32_t)plan.deferred_equal.size();
             r->plan_level_ofs = plan.level_ofs;
             r->plan_written = plan.written;
             r->plan_n_in = hc.n_in;
@@ -1808,7 +1815,8 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     for (size_t l = 0; l < n_levels; ++l) {
         const uint32_t lo = r->plan_level_ofs[l], cnt = r->plan_level_ofs[l + 1] - lo;
         if (cnt == 0) continue;
-        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo, r->ev_cols + (size_t)lo * kEvalLanes};
+        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo, r->ev_cols + (size_t)lo * kEvalLanes,
+                          r->ev_defer_magic ? 1u : 0u};
         if (cnt < lanes_below) {
             const uint32_t per_block = kBlock / kEvalLanes;
             DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level_lanes<F>), dim3((cnt + per_block - 1) / per_block), dim3(kBlock), 0, cur_stream(c),
@@ -1818,6 +1826,9 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
                                                  G, A, B, r->d_w));
         }
     }
+    if (r->n_ev_equal)
+        DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_magic<F>), dim3((r->n_ev_equal + kSlice - 1) / kSlice), dim3(kSlice), 0, cur_stream(c),
+                                             (const u32*)r->ev_equal, r->n_ev_equal, (const u32*)r->ev_wire_ofs, (const u32*)r->ev_wires, r->d_w));
     HIP_TRY(hipGetLastError());
     r->resident_valid = true;
     if (witness) {

@@ -858,6 +858,7 @@ __global__ __launch_bounds__(kBlock) void k_any_nonzero(const uint4* __restrict_
 // by earlier levels, so a level is one data-parallel launch.  Mul: out = <A_row,w> * <B_row,w>, the
 // gate's own constraint row (src/QAP.hs:371-395); Equal: out = (inp /= 0), magic = inp^-1 (Fermat);
 // Split: bit j of the canonical integer.
+constexpr u32 kEvalLanes = 8;   // lanes per gate in k_eval_level_lanes
 struct EvalGates {
     const u32* items;        // gate ids of this level
     u32 count;
@@ -867,6 +868,7 @@ struct EvalGates {
     const u32* wires;        // flat wire indices: Mul {out}, Equal {i, m, out}, Split {inp, outs...}
     const uint4* mul;        // per item, level order: Mul gate {out wire, first A entry, first B entry, nA | nB << 16}, else .w = ~0
     const u32* cols;         // per item, level order: kEvalLanes columns (entries 0-3 of the A row, 0-3 of the B row; k_eval_fill_cols)
+    u32 defer_magic;         // Equal gates leave their magic wire to k_eval_magic (no gate reads one: HostCircuit::build_plan)
 };
 
 // one gate of any kind on one lane (everything except the recorded Mul gates of a level)
@@ -881,14 +883,56 @@ __device__ __forceinline__ void eval_gate_generic(const EvalGates& G, const CsrD
     } else if (kd == 1) {                                     // Equal
         const Fe inp = fe_load(w + 2 * (u64)gw[0]);
         const bool z = fe_is_zero<F>(inp);
-        fe_store(w + 2 * (u64)gw[1], z ? fe_zero() : fe_inv_divsteps<F>(inp));
         fe_store(w + 2 * (u64)gw[2], z ? fe_zero() : fe_one_mont<F>());
+        if (!G.defer_magic) fe_store(w + 2 * (u64)gw[1], z ? fe_zero() : fe_inv_divsteps<F>(inp));
     } else {                                                  // Split
         const Fe c = fe_from_mont<F>(fe_load(w + 2 * (u64)gw[0]));
         const u32 n_out = G.wire_ofs[g + 1] - G.wire_ofs[g] - 1;
         for (u32 j = 0; j < n_out; ++j) {
             const bool bit = j < 256 && ((c.l[j / kLimbBits] >> (j % kLimbBits)) & 1u);
             fe_store(w + 2 * (u64)gw[1 + j], bit ? fe_one_mont<F>() : fe_zero());
+        }
+    }
+}
+
+// The magic wires of ALL Equal gates (magic = inp^-1, 0 for inp = 0; src/Circuit/Arithmetic.hs:117-131), one lane per gate,
+// after the last level: an inversion is ~20 000 dependent instructions, and inside the levels it would be the latency of
+// every level that holds an Equal gate (the gate's OUTPUT, the only thing later gates may read, is a zero test).
+template <class F>
+__global__ __launch_bounds__(kSlice) void k_eval_magic(const u32* __restrict__ gates, u32 count, const u32* __restrict__ wire_ofs,
+                                                       const u32* __restrict__ wires, uint4* __restrict__ w) {
+    const u32 t = blockIdx.x * kSlice + threadIdx.x;
+    if (t >= count) return;
+    const u32* gw = wires + wire_ofs[gates[t]];
+    const Fe inp = fe_load(w + 2 * (u64)gw[0]);
+    fe_store(w + 2 * (u64)gw[1], fe_is_zero<F>(inp) ? fe_zero() : fe_inv_divsteps<F>(inp));
+}
+
+// A Split gate on the kEvalLanes lanes of its group (k_eval_level_lanes): lane `sub` writes output bits [32 c, 32 c + 32) for
+// c = sub, sub + kEvalLanes, ... -- one word of the packed canonical value each.  On one lane the 256 stores (and their wire
+// lookups) were ~50 us of the level's latency; bits past 255 are zero (a canonical value is below 2^256).
+template <class F>
+__device__ __forceinline__ void eval_split_lanes(const EvalGates& G, uint4* __restrict__ w, u32 g, u32 sub) {
+    const u32* gw = G.wires + G.wire_ofs[g];
+    const u32 n_out = G.wire_ofs[g + 1] - G.wire_ofs[g] - 1;
+    u32 words[8], one[8];
+    fe_pack(fe_from_mont<F>(fe_load(w + 2 * (u64)gw[0])), words);
+    fe_pack(fe_one_mont<F>(), one);
+#pragma unroll 1
+    for (u32 base = 32u * sub; base < n_out; base += 32u * kEvalLanes) {
+        u32 wd = 0;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) wd = (base >> 5) == q ? words[q] : wd;
+        const u32 end = min(32u, n_out - base);
+#pragma unroll 4
+        for (u32 i = 0; i < end; ++i) {
+            const u32 m = 0u - ((wd >> i) & 1u);
+            v4u32 lo, hi;
+            lo.x = one[0] & m; lo.y = one[1] & m; lo.z = one[2] & m; lo.w = one[3] & m;
+            hi.x = one[4] & m; hi.y = one[5] & m; hi.z = one[6] & m; hi.w = one[7] & m;
+            uint4* p = w + 2 * (u64)gw[1 + base + i];
+            *(g_v4u32_t*)p = lo;
+            *(g_v4u32_t*)(p + 1) = hi;
         }
     }
 }
@@ -918,7 +962,6 @@ __global__ __launch_bounds__(kBlock) void k_eval_level(EvalGates G, CsrDev A, Cs
 // {column, value} -> witness, and ~650 instructions.  Other gate kinds run on lane 0 of their group as before.
 // The chain is record -> {column, value} -> witness; the level-ordered column copy (G.cols, 32 bytes per item) takes the
 // column out of it: a lane's column address depends on nothing but its index, so it is record -> value beside column -> witness.
-constexpr u32 kEvalLanes = 8;
 __global__ __launch_bounds__(kBlock) void k_eval_fill_cols(const uint4* __restrict__ mul, u32 count, const u32* __restrict__ col_a,
                                                           const u32* __restrict__ col_b, u32* __restrict__ cols) {
     const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
@@ -973,12 +1016,14 @@ __global__ __launch_bounds__(kBlock) void k_eval_level_lanes(EvalGates G, CsrDev
     Fe other;
 #pragma unroll
     for (int i = 0; i < kLimbs; ++i) other.l[i] = (u32)__shfl_xor((int)part.l[i], (int)kEvalLanes / 2, kSlice);
-    if (!live || sub != 0) return;
+    if (!live) return;
     if (is_mul) {
-        fe_store(w + 2 * (u64)it.x, fe_mul<F>(part, other));
+        if (sub == 0) fe_store(w + 2 * (u64)it.x, fe_mul<F>(part, other));
         return;
     }
-    eval_gate_generic<F>(G, A, B, w, G.items[t]);
+    const u32 g = G.items[t];
+    if (G.kind[g] == 2) eval_split_lanes<F>(G, w, g, sub);
+    else if (sub == 0) eval_gate_generic<F>(G, A, B, w, g);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1645,6 +1645,41 @@ def test_equal_gate_inversion_edge_values(request, acx, field):
     assert r.verify_resident()[0]
 
 
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("magic_is_read", [False, True])
+def test_equal_gate_magic_wires_after_the_levels(request, acx, field, magic_is_read):
+    """acx_r1cs_eval computes the magic wires (inp^-1, src/Circuit/Arithmetic.hs:117-131) of all Equal gates in ONE launch
+    after the last level when no gate reads one (what validArithCircuit guarantees); a circuit in which a later Mul gate DOES
+    read a magic wire (the reference's evalGate would let it) keeps the inversion inside the level.  A chain of Equal ->
+    Mul -> Equal ... so that every level holds an Equal gate; witness bit for bit against the host fold and big integers."""
+    ctx = _ctx(request, field)
+    p = ctx.p
+    rnd = random.Random(4242 + magic_is_read)
+    n = 40
+    I, M, V = acx.InputWire, acx.IntermediateWire, acx.Var
+    gates = []
+    cur = I(0)
+    for k in range(n):
+        m, o, t = M(3 * k), M(3 * k + 1), M(3 * k + 2)
+        gates.append(acx.Equal(cur, m, o))
+        # t = (o + c) * (x1 [+ magic]): depends on the Equal gate's output, and on its magic wire in the second form
+        right = acx.Add(V(I(1)), V(m)) if magic_is_read else V(I(1))
+        gates.append(acx.Mul(acx.Add(V(o), acx.ConstGate(rnd.randrange(p))), right, t))
+        cur = t
+    circ = acx.ArithCircuit(gates).marshal(field)
+    r = circ.to_r1cs(ctx)
+    for x0 in (0, 5, rnd.randrange(p)):
+        inp = acx.ints_to_fr([x0, rnd.randrange(1, p)])
+        want, want_as = circ.eval(inp)
+        got, got_as = r.eval_witness(inp)
+        assert np.array_equal(got, want) and np.array_equal(got_as, want_as)
+        wi = acx.fr_to_ints(got)
+        for k in range(n):
+            v = wi[1 + (0 if k == 0 else 2 + 3 * (k - 1) + 2)]
+            assert (wi[3 + 3 * k], wi[3 + 3 * k + 1]) == ((pow(v, -1, p), 1) if v else (0, 0))
+        assert r.verify_resident()[0]
+
+
 # ------------------------------------------------------------------ f-2: aeson-shaped JSON through the HIP path
 def test_json_loaded_example_runs_on_the_device(request, acx):
     """SURVEY.md 8f-2 on the device: tests/golden/aeson_example_circuit.json + aeson_example_assignment.json (the
