@@ -1680,6 +1680,35 @@ def test_equal_gate_magic_wires_after_the_levels(request, acx, field, magic_is_r
         assert r.verify_resident()[0]
 
 
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+def test_split_gate_widths_on_the_lanes(request, acx, field):
+    """k_eval_level_lanes writes a Split gate's bit wires with the gate's eight lanes, 32 bits of the canonical value per lane
+    and turn: widths 1 .. 300 (ragged last words, more than one turn per lane, bits past the field's 255), inputs 0, p - 1,
+    2^k and random values -- against the host fold (src/Circuit/Arithmetic.hs:132-145) and the integer's own bits."""
+    ctx = _ctx(request, field)
+    p = ctx.p
+    rnd = random.Random(77)
+    widths = [1, 2, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 300]
+    I, M = acx.InputWire, acx.IntermediateWire
+    gates, first, nxt = [], [], 0
+    for k, wd in enumerate(widths):
+        first.append(nxt)
+        gates.append(acx.Split(I(k), [M(nxt + j) for j in range(wd)]))
+        nxt += wd
+    circ = acx.ArithCircuit(gates).marshal(field)
+    r = circ.to_r1cs(ctx)
+    n_in = len(widths)
+    for t in range(4):
+        vals = [[0, p - 1, 1 << (k % 254), rnd.randrange(p)][(t + k) % 4] for k in range(n_in)]
+        inp = acx.ints_to_fr(vals)
+        want, want_as = circ.eval(inp)
+        got, got_as = r.eval_witness(inp)
+        assert np.array_equal(got, want) and np.array_equal(got_as, want_as)
+        wi = acx.fr_to_ints(got)
+        for k, wd in enumerate(widths):
+            assert wi[1 + n_in + first[k]: 1 + n_in + first[k] + wd] == [(vals[k] >> j) & 1 for j in range(wd)]
+
+
 # ------------------------------------------------------------------ f-2: aeson-shaped JSON through the HIP path
 def test_json_loaded_example_runs_on_the_device(request, acx):
     """SURVEY.md 8f-2 on the device: tests/golden/aeson_example_circuit.json + aeson_example_assignment.json (the
