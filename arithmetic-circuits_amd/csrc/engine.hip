@@ -232,11 +232,13 @@ struct acx_r1cs {
     uint8_t* ev_kind = nullptr;
     uint4* ev_mul = nullptr;             // per plan item: the Mul gate's record (k_eval_level)
     u32* ev_cols = nullptr;              // per plan item: kEvalLanes columns (k_eval_level_lanes)
+    u32* ev_level_ofs = nullptr;         // plan_level_ofs on the device (k_eval_levels_fused)
     u32* ev_equal = nullptr;             // Equal gates whose magic wires k_eval_magic fills after the last level (n_ev_equal of them)
     uint32_t n_ev_equal = 0;
     bool ev_defer_magic = false;
     bool has_csc = false;
     uint4* d_w = nullptr;  // the witness acx_r1cs_eval leaves resident (m elements); acx_naive_h uses it as scratch
+    uint4* d_w_canon = nullptr;                      // conversion target of acx_r1cs_eval's witness download (first use; hipMalloc / hipFree synchronise the device)
     bool resident_valid = false;                     // d_w holds a witness produced by acx_r1cs_eval
     uint4* qh = nullptr;   // h(x) pipeline scratch, 5N elements (allocated on first use)
     uint4* d_hscale = nullptr;       // {1/z, -1/z} as dev elements: the factors the h(x) pipeline lets ride on the stored dot products
@@ -1183,6 +1185,8 @@ void free_r1cs_device(acx_r1cs* r) {
     if (r->ev_mul) { (void)hipFree(r->ev_mul); r->ev_mul = nullptr; }
     if (r->ev_cols) { (void)hipFree(r->ev_cols); r->ev_cols = nullptr; }
     if (r->ev_equal) { (void)hipFree(r->ev_equal); r->ev_equal = nullptr; }
+    if (r->ev_level_ofs) { (void)hipFree(r->ev_level_ofs); r->ev_level_ofs = nullptr; }
+    if (r->d_w_canon) { (void)hipFree(r->d_w_canon); r->d_w_canon = nullptr; }
     if (r->ev_items) (void)hipFree(r->ev_items);
     if (r->ev_row) (void)hipFree(r->ev_row);
     if (r->ev_wire_ofs) (void)hipFree(r->ev_wire_ofs);
@@ -1586,6 +1590,7 @@ static void ensure_eval_plan(acx_r1cs* r) {
             up((void**)&r->ev_wire_ofs, wofs.data(), wofs.size() * 4) && up((void**)&r->ev_wires, wflat.data(), wflat.size() * 4) &&
             up((void**)&r->ev_kind, hc.kind.data(), hc.kind.size()) && up((void**)&r->ev_mul, mul.data(), mul.size() * 4) &&
             up((void**)&r->ev_equal, plan.deferred_equal.data(), plan.deferred_equal.size() * 4) &&
+            up((void**)&r->ev_level_ofs, plan.level_ofs.data(), plan.level_ofs.size() * 4) &&
             hipMalloc((void**)&r->ev_cols, plan.items.size() * kEvalLanes * 4 + 4) == hipSuccess) {
             // level-ordered copy of the first four columns of each recorded Mul gate's A and B rows (k_eval_level_lanes)
             const uint64_t lanes = (uint64_t)plan.items.size() * kEvalLanes;
@@ -1806,17 +1811,34 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     w0[0].b[0] = 1;
     for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) w0[1 + i] = inputs[i];
     r->resident_valid = false;
+    // no host round trip before the levels: the canonicity flag of the inputs comes back with the call's result slot
+    ACX_TRY(begin_call(c));
     HIP_TRY(hipMemsetAsync(r->d_w, 0, r->m * 32, cur_stream(c)));
-    ACX_TRY(upload_elements(c, w0.data(), w0.size(), r->d_w));
+    ACX_TRY(upload_elements_async(c, w0.data(), w0.size(), r->d_w));
     const CsrDev A{r->M[0].ptr, r->M[0].idx, r->M[0].val}, B{r->M[1].ptr, r->M[1].idx, r->M[1].val};
     const size_t n_levels = r->plan_level_ofs.size() - 1;
     // narrow levels are latency: eight lanes per gate (k_eval_level_lanes); wide ones throughput: a lane per gate
     static const uint32_t lanes_below = [] { const char* e = getenv("ACX_EVAL_LANES_BELOW"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 32768u; }();
-    for (size_t l = 0; l < n_levels; ++l) {
-        const uint32_t lo = r->plan_level_ofs[l], cnt = r->plan_level_ofs[l + 1] - lo;
+    // runs of narrow levels (<= kEvalFusedGates gates each) go to ONE workgroup in ONE launch: a level costs a barrier there
+    static const bool fuse = [] { const char* e = getenv("ACX_EVAL_FUSED"); return !e || strcmp(e, "0") != 0; }();
+    auto width = [&](size_t l) { return r->plan_level_ofs[l + 1] - r->plan_level_ofs[l]; };
+    const uint32_t dm = r->ev_defer_magic ? 1u : 0u;
+    for (size_t l = 0; l < n_levels;) {
+        const uint32_t lo = r->plan_level_ofs[l], cnt = width(l);
+        if (fuse && cnt <= kEvalFusedGates) {
+            size_t e = l + 1;
+            while (e < n_levels && width(e) <= kEvalFusedGates) ++e;
+            if (e - l >= 2) {
+                const EvalGates G{r->ev_items, 0u, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul, r->ev_cols, dm};
+                DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_levels_fused<F>), dim3(1), dim3(kEvalFusedBlock), 0, cur_stream(c),
+                                                     G, (const u32*)r->ev_level_ofs, (u32)l, (u32)e, A, B, r->d_w));
+                l = e;
+                continue;
+            }
+        }
+        ++l;
         if (cnt == 0) continue;
-        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo, r->ev_cols + (size_t)lo * kEvalLanes,
-                          r->ev_defer_magic ? 1u : 0u};
+        const EvalGates G{r->ev_items + lo, cnt, r->ev_kind, r->ev_row, r->ev_wire_ofs, r->ev_wires, r->ev_mul + lo, r->ev_cols + (size_t)lo * kEvalLanes, dm};
         if (cnt < lanes_below) {
             const uint32_t per_block = kBlock / kEvalLanes;
             DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_level_lanes<F>), dim3((cnt + per_block - 1) / per_block), dim3(kBlock), 0, cur_stream(c),
@@ -1830,14 +1852,16 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
         DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_magic<F>), dim3((r->n_ev_equal + kSlice - 1) / kSlice), dim3(kSlice), 0, cur_stream(c),
                                              (const u32*)r->ev_equal, r->n_ev_equal, (const u32*)r->ev_wire_ofs, (const u32*)r->ev_wires, r->d_w));
     HIP_TRY(hipGetLastError());
-    r->resident_valid = true;
+    CallSlot slot;
     if (witness) {
-        DevBuf tmp;
-        ACX_TRY(tmp.alloc(r->m * 32));
-        ACX_TRY(download_elements(c, r->d_w, r->m, witness, tmp.as<uint4>()));
-    } else {
-        HIP_TRY(hipStreamSynchronize(cur_stream(c)));
+        if (!r->d_w_canon) HIP_TRY(hipMalloc((void**)&r->d_w_canon, r->m * 32));
+        ACX_TRY(launch_convert(c, false, r->d_w, r->d_w_canon, r->m, nullptr));
+        HIP_TRY(hipMemcpyAsync(witness, r->d_w_canon, r->m * 32, hipMemcpyDeviceToHost, cur_stream(c)));
     }
+    ACX_TRY(end_call_fetch(c, &slot));
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
+    if (slot.noncanonical) return fail(ACX_ERR_NONCANONICAL, "element >= p");
+    r->resident_valid = true;
     if (assigned) std::memcpy(assigned, as.data(), as.size());
     return ACX_OK;
 }

@@ -979,16 +979,11 @@ __global__ __launch_bounds__(kBlock) void k_eval_fill_cols(const uint4* __restri
     cols[i] = c;
 }
 
+// one level's worth of work of one lane: group t of the level, lane `sub` of the group; `it` / `my_col` are the group's record and the
+// lane's first column (loaded by the caller: the fused kernel fetches the next level's while this level computes)
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_eval_level_lanes(EvalGates G, CsrDev A, CsrDev B, uint4* __restrict__ w) {
-    const u32 t = (blockIdx.x * kBlock + threadIdx.x) / kEvalLanes, sub = threadIdx.x % kEvalLanes;
-    const bool live = t < G.count;
-    uint4 it = make_uint4(0u, 0u, 0u, 0xffffffffu);
-    u32 my_col = 0;
-    if (live) {
-        it = gload(G.mul + t);
-        my_col = gload(G.cols + (u64)t * kEvalLanes + sub);
-    }
+__device__ __forceinline__ void eval_lanes_body(const EvalGates& G, const CsrDev& A, const CsrDev& B, uint4* __restrict__ w, u32 t, u32 sub,
+                                                bool live, const uint4 it, u32 my_col) {
     const bool is_mul = it.w != 0xffffffffu;
     Fe part = fe_zero();
     if (is_mul) {
@@ -1024,6 +1019,57 @@ __global__ __launch_bounds__(kBlock) void k_eval_level_lanes(EvalGates G, CsrDev
     const u32 g = G.items[t];
     if (G.kind[g] == 2) eval_split_lanes<F>(G, w, g, sub);
     else if (sub == 0) eval_gate_generic<F>(G, A, B, w, g);
+}
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_eval_level_lanes(EvalGates G, CsrDev A, CsrDev B, uint4* __restrict__ w) {
+    const u32 t = (blockIdx.x * kBlock + threadIdx.x) / kEvalLanes, sub = threadIdx.x % kEvalLanes;
+    const bool live = t < G.count;
+    uint4 it = make_uint4(0u, 0u, 0u, 0xffffffffu);
+    u32 my_col = 0;
+    if (live) {
+        it = gload(G.mul + t);
+        my_col = gload(G.cols + (u64)t * kEvalLanes + sub);
+    }
+    eval_lanes_body<F>(G, A, B, w, t, sub, live, it, my_col);
+}
+
+// A RUN of consecutive levels of at most kEvalFusedGates (128) gates each (a small or narrow circuit: the reference's own
+// benchmark circuit, a 2^10-gate chain) in ONE launch of ONE workgroup: a level boundary is a workgroup barrier (~0.1 us)
+// instead of a kernel boundary (~3 us of launch and first-touch latency), and the next level's records are in flight while this
+// level computes.  The waves of a workgroup share their CU's write-through L1, so a wire stored before the barrier is what a
+// load after it returns (workgroup-scope release / acquire = __syncthreads).  G.items / G.mul / G.cols are the WHOLE plan's arrays here.
+constexpr u32 kEvalFusedBlock = 1024;
+constexpr u32 kEvalFusedGates = kEvalFusedBlock / kEvalLanes;
+template <class F>
+__global__ __launch_bounds__(kEvalFusedBlock) void k_eval_levels_fused(EvalGates G, const u32* __restrict__ level_ofs, u32 l0, u32 l1, CsrDev A, CsrDev B,
+                                                              uint4* __restrict__ w) {
+    const u32 t = threadIdx.x / kEvalLanes, sub = threadIdx.x % kEvalLanes;
+    u32 lo = sload(level_ofs + l0), hi = sload(level_ofs + l0 + 1);
+    uint4 it = make_uint4(0u, 0u, 0u, 0xffffffffu);
+    u32 my_col = 0;
+    if (t < hi - lo) {
+        it = gload(G.mul + lo + t);
+        my_col = gload(G.cols + (u64)(lo + t) * kEvalLanes + sub);
+    }
+#pragma unroll 1
+    for (u32 l = l0; l < l1; ++l) {
+        const bool live = t < hi - lo;
+        EvalGates L = G;
+        L.items = G.items + lo;
+        L.count = hi - lo;
+        // the next level's record and column do not depend on this level's results
+        const u32 nlo = hi, nhi = l + 1 < l1 ? sload(level_ofs + l + 2) : hi;
+        uint4 nit = make_uint4(0u, 0u, 0u, 0xffffffffu);
+        u32 ncol = 0;
+        if (t < nhi - nlo) {
+            nit = gload(G.mul + nlo + t);
+            ncol = gload(G.cols + (u64)(nlo + t) * kEvalLanes + sub);
+        }
+        eval_lanes_body<F>(L, A, B, w, t, sub, live, it, my_col);
+        __syncthreads();
+        it = nit; my_col = ncol; lo = nlo; hi = nhi;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -217,7 +217,7 @@ def reference_bench(ctx, field="bn254"):
     out["evalArithCircuit"] = {"gpu_acx_r1cs_eval_s": wall(lambda: r.eval_witness(s.inputs), 20),
                                "gpu_resident_no_download_s": wall(lambda: r.eval_witness(s.inputs, download=False), 20),
                                "host_acx_circuit_eval_s": wall(lambda: c.eval(s.inputs), 20), "parity_vs_oracle": ok_eval,
-                               "note": "a 2^10-gate chain has ~10^3 levels of one gate or a few: launch-latency bound on a GPU; the host fold is the fast path at this size"}
+                               "note": "23 dependency levels of at most 88 gates: ONE launch of one workgroup (k_eval_levels_fused, ~3 us of dependent latency per level) + input upload and result fetch; latency bound, on a par with the host fold at this size"}
 
     # 2. arithCircuitToGenQAP: acx_circuit_create + acx_circuit_to_r1cs
     def gen_qap():

@@ -221,7 +221,8 @@ int acx_r1cs_verify(acx_r1cs* r, const acx_fr* witness, int* ok, uint64_t* n_bad
 int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, uint8_t* ok, uint64_t* n_bad,
                          uint64_t* first_bad);
 /* `generateAssignment` on the GPU: the gates are evaluated level by level (a
- * level = gates whose inputs are all produced by earlier levels), one launch per level; Mul gates
+ * level = gates whose inputs are all produced by earlier levels), one launch per level (one launch
+ * per RUN of levels of at most 128 gates: small circuits are a single launch); Mul gates
  * reuse their own constraint rows; the magic wires of Equal gates (inverses, read by no gate of a
  * valid circuit) are filled by one launch after the last level -- inside the levels when some gate does read one.  Available for systems built by acx_circuit_to_r1cs from a
  * circuit in single-assignment form (else ACX_ERR_UNSUPPORTED: use acx_circuit_eval).  Same

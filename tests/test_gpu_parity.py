@@ -1680,6 +1680,31 @@ def test_equal_gate_magic_wires_after_the_levels(request, acx, field, magic_is_r
         assert r.verify_resident()[0]
 
 
+def test_gpu_witness_generation_small_circuit_one_launch_and_input_checks(request, acx):
+    """A circuit whose levels are all narrow (the reference's benchmark shape: a 2^10-gate mulgraph has 23 levels of at most
+    88 gates) is evaluated by ONE workgroup in one launch (k_eval_levels_fused; ACX_EVAL_FUSED=0 is the launch-per-level
+    form): same witness as the host fold, repeatedly on the same handle; a non-canonical input is refused (and leaves no
+    resident witness behind), after which the handle evaluates again."""
+    ctx = _ctx(request, "bn254")
+    s = acx.synth.mulgraph(1 << 10, seed=0xAC0)
+    r = s.circuit.to_r1cs(ctx)
+    want, want_as = s.circuit.eval(s.inputs)
+    for _ in range(3):
+        got, got_as = r.eval_witness(s.inputs)
+        assert np.array_equal(got, want) and np.array_equal(got_as, want_as)
+        assert r.verify_resident() == (True, 0, 2**64 - 1)
+    bad = s.inputs.copy()
+    bad[3] = np.array([2**64 - 1] * 4, dtype=np.uint64)                 # >= p
+    with pytest.raises(acx.AcxError) as e:
+        r.eval_witness(bad)
+    assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
+    with pytest.raises(acx.AcxError):
+        r.verify_resident()
+    got, _ = r.eval_witness(s.inputs, download=False)
+    assert got is None and r.verify_resident()[0]
+    r.close()
+
+
 @pytest.mark.parametrize("field", ["bn254", "bls12_381"])
 def test_split_gate_widths_on_the_lanes(request, acx, field):
     """k_eval_level_lanes writes a Split gate's bit wires with the gate's eight lanes, 32 bits of the canonical value per lane
