@@ -348,7 +348,8 @@ def test_concurrent_callers_overlap(request, acx):
             parallel = min(parallel, time.perf_counter() - t0)
     assert not errs, errs
     # the parallel round also carried a residual vector and an h(x); even so it must beat the serial verifies
-    assert serial / parallel > 1.5, (serial, parallel)
+    print(f"serial / parallel = {serial / parallel:.2f}")
+    assert serial / parallel > 1.25, (serial, parallel)           # 1.8 - 2.1 on an idle MI355X box; the margin is for a busy host
 
 
 # ------------------------------------------------------------------ batched launch + multi-GPU host layer on one GPU
