@@ -4,7 +4,9 @@ fold: the oracle's literal evalArithCircuit (oracle/ref_qap.py, small circuits) 
 (all sizes).  Circuits in the reference's generator shapes (test/Test/Circuit/Arithmetic.hs:69-126) with what its generator
 never produces added: Split gates of every width (1 .. 300), Equal gates on zero, gates that READ an Equal gate's magic wire
 (evalGate allows it, validArithCircuit does not: the inversions then stay inside the levels), absent inputs, and the same
-circuits through the one-lane-per-gate kernel of wide levels (ACX_EVAL_LANES_BELOW=0 in a second process).
+circuits through the one-lane-per-gate kernel of wide levels (ACX_EVAL_LANES_BELOW=0 ACX_EVAL_FUSED=0 in a second process:
+without the second variable runs of narrow levels still go to k_eval_levels_fused) and through the launch-per-level form of
+the lanes kernel (ACX_EVAL_FUSED=0 alone).
     python tools/fuzz_eval.py [cases] [first]"""
 import importlib, os, random, sys, time
 import numpy as np
@@ -104,7 +106,7 @@ def main(cases, first):
             bad += 1
             print("MISMATCH", tag, e, flush=True)
     print(f"fuzz_eval: {cases} cases from seed {first}, {bad} failures, {time.time() - t0:.0f} s"
-          f"{' (ACX_EVAL_LANES_BELOW=' + os.environ['ACX_EVAL_LANES_BELOW'] + ')' if 'ACX_EVAL_LANES_BELOW' in os.environ else ''}")
+          + "".join(f" ({k}={os.environ[k]})" for k in ("ACX_EVAL_LANES_BELOW", "ACX_EVAL_FUSED") if k in os.environ))
     return 1 if bad else 0
 
 
