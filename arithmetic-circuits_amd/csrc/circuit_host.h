@@ -28,11 +28,6 @@
 
 namespace acx {
 
-struct SparseRow {
-    std::vector<uint32_t> col;
-    std::vector<H256> val;  // Montgomery (host radix)
-};
-
 // Worker threads for the host-side loops over gates / scalars (row generation is the reference's
 // arithCircuitToGenQAP, src/QAP.hs:530-539).  ACX_HOST_THREADS overrides the count.
 // CPUs this process may really use: the hardware threads, cut by a cgroup CPU quota when there is one (cpu.max = "quota
@@ -117,12 +112,12 @@ struct HostCsr {
     std::vector<uint32_t> rowptr{0};
     RawVec<uint32_t> col;
     RawVec<H256> val;  // canonical
-    template <class Row>     // any range of (column, Montgomery value) pairs in ascending column order
-    void push_row(const HostField& hf, const Row& row) {
+    template <class Row>     // any range of (column, CANONICAL value) pairs in ascending column order
+    void push_row(const HostField&, const Row& row) {
         for (const auto& kv : row) {
             if (kv.second.is_zero()) continue;  // explicit zeros of the reference are numerically void
             col.push_back((uint32_t)kv.first);
-            val.push_back(hf.from_mont(kv.second));
+            val.push_back(kv.second);
         }
         rowptr.push_back((uint32_t)col.size());
     }
@@ -136,7 +131,21 @@ public:
     RawVec<uint64_t> tok_ofs;
     RawVec<uint8_t> tok_op;
     RawVec<uint32_t> tok_arg;
-    RawVec<H256> scalars;  // Montgomery
+    RawVec<H256> scalars;  // canonical
+    mutable RawVec<H256> scalars_mont;         // Montgomery copy for the host fold (eval), made on first use
+    mutable std::once_flag scalars_mont_once;
+    const H256* mont_scalars() const {
+        std::call_once(scalars_mont_once, [&] {
+            scalars_mont.resize(scalars.size());
+            parallel_ranges(scalars.size(), host_threads(scalars.size(), 1 << 16), [&](unsigned, uint64_t b, uint64_t e) {
+                for (uint64_t i = b; i < e; ++i) scalars_mont[i] = hf.to_mont(scalars[i]);
+            });
+        });
+        return scalars_mont.data();
+    }
+    // canonical constants and the canonical product of two canonical values ((a b / R) R^2 / R)
+    static H256 c_one() { return H256{{1, 0, 0, 0}}; }
+    H256 cmul(const H256& a, const H256& b) const { return hf.to_mont(hf.mul(a, b)); }
     RawVec<acx_wire> aff_wires;
     RawVec<uint64_t> wire_ofs;
     RawVec<acx_wire> wires;
@@ -185,6 +194,11 @@ public:
         if (n_tok) { parallel_copy(tok_op, gl->tok_op, n_tok); parallel_copy(tok_arg, gl->tok_arg, n_tok); }
         if (n_w) parallel_copy(wires, gl->wires, n_w);
         if (gl->n_aff_wires) parallel_copy(aff_wires, gl->aff_wires, gl->n_aff_wires);
+        // The scalars stay CANONICAL, as the caller gave them and as the rows leave this class: gateToGenQAP only adds
+        // coefficients, and multiplies two of them where ScalarMul nodes nest (cmul: two Montgomery products there) -- a flat
+        // side s * Var x costs no multiplication at all, where converting every scalar in and every row entry out cost two
+        // (2/3 of acx_circuit_create on the reference's benchmark circuit).  The host fold wants Montgomery operands and makes
+        // its own copy on first use (mont_scalars).
         scalars.resize(gl->n_scalars);
         {
             std::atomic<bool> noncanonical{false};
@@ -193,7 +207,7 @@ public:
                     H256 c;
                     std::memcpy(c.l, gl->scalars[i].b, 32);
                     if (!hf.is_canonical(c)) { noncanonical = true; return; }
-                    scalars[i] = hf.to_mont(c);
+                    scalars[i] = c;
                 }
             });
             if (noncanonical) { msg = "scalar >= p"; return ACX_ERR_NONCANONICAL; }
@@ -249,22 +263,22 @@ public:
     // s c to the constant, Var x emits the term (x, s).  Scaling distributes over Map.unionWith (+) exactly in a field, so the
     // terms of one wire, summed at the end, are the reference's map entry -- including the wire whose coefficients cancel, which
     // stays with value 0.  No recursion and no allocation per node: a 10^5-term Add chain costs one stack of scales.
-    // `vec` comes back ascending and unique by column.
+    // `vec` comes back ascending and unique by column; coefficients and `cst` canonical.
     void affine_map(uint64_t begin, uint64_t end, H256& cst, Entries& vec) const {
         static thread_local std::vector<H256> st;
         st.clear();
-        st.push_back(hf.one());
+        const H256 one = c_one();
+        st.push_back(one);
         vec.clear();
         cst = hf.zero();
-        const H256 one = hf.one();
         for (uint64_t pos = begin; pos < end; ++pos) {
             const H256 sc = st.back();
             st.pop_back();
             const uint8_t op = tok_op[pos];
             const uint32_t arg = tok_arg[pos];
             if (op == ACX_AFF_VAR) vec.emplace_back(flat(aff_wires[arg]), sc);
-            else if (op == ACX_AFF_CONST) cst = hf.add(cst, sc == one ? scalars[arg] : hf.mul(sc, scalars[arg]));
-            else if (op == ACX_AFF_SCALARMUL) st.push_back(sc == one ? scalars[arg] : hf.mul(sc, scalars[arg]));
+            else if (op == ACX_AFF_CONST) cst = hf.add(cst, sc == one ? scalars[arg] : cmul(sc, scalars[arg]));
+            else if (op == ACX_AFF_SCALARMUL) st.push_back(sc == one ? scalars[arg] : cmul(sc, scalars[arg]));
             else { st.push_back(sc); st.push_back(sc); }
         }
         if (vec.size() > 1) {
@@ -283,8 +297,8 @@ public:
     }
 
     // evalAffineCircuit of the tokens [begin, end): failed lookups are 0.  Same right-to-left evaluation.
-    H256 affine_eval(uint64_t begin, uint64_t end, const std::vector<H256>& w, const std::vector<uint8_t>& assigned) const {
-        std::vector<H256> st;
+    H256 affine_eval(uint64_t begin, uint64_t end, const std::vector<H256>& w, const std::vector<uint8_t>& assigned, const H256* scalars) const {
+        std::vector<H256> st;                  // `scalars`: mont_scalars() -- the witness is kept in Montgomery form
         for (uint64_t pos = end; pos-- > begin;) {
             const uint8_t op = tok_op[pos];
             const uint32_t arg = tok_arg[pos];
@@ -341,7 +355,7 @@ public:
     using RowMaps = std::array<Entries, 3>;
     // returns the gate's row count; rows[0 .. count) are filled (the vector only grows: its inner buffers are reused gate after gate)
     size_t gate_rows(uint64_t g, std::vector<RowMaps>& rows) const {
-        const H256 one = hf.one(), minus_one = hf.neg(hf.one()), zero = hf.zero();
+        const H256 one = c_one(), minus_one = hf.neg(c_one()), zero = hf.zero();      // canonical, like every row value
         const acx_wire* gw = &wires[wire_ofs[g]];
         const size_t count = rows_of_gate(g);
         if (rows.size() < count) rows.resize(count);
@@ -451,6 +465,7 @@ public:
     // generateAssignment.  inputs canonical.  Returns ACX_OK / ACX_ERR_UNDEFINED_WIRE.
     int eval(const acx_fr* inputs, const uint8_t* present, uint64_t n_inputs, std::vector<H256>& w,
              std::vector<uint8_t>& assigned, std::string& msg) const {
+        const H256* sm = mont_scalars();
         w.assign(m(), hf.zero());
         assigned.assign(m(), 0);
         w[0] = hf.one();
@@ -466,8 +481,8 @@ public:
         for (uint64_t g = 0; g < n_gates; ++g) {
             const acx_wire* gw = &wires[wire_ofs[g]];
             if (kind[g] == ACX_GATE_MUL) {
-                const H256 l = affine_eval(tok_ofs[2 * g], tok_ofs[2 * g + 1], w, assigned);
-                const H256 r = affine_eval(tok_ofs[2 * g + 1], tok_ofs[2 * g + 2], w, assigned);
+                const H256 l = affine_eval(tok_ofs[2 * g], tok_ofs[2 * g + 1], w, assigned, sm);
+                const H256 r = affine_eval(tok_ofs[2 * g + 1], tok_ofs[2 * g + 2], w, assigned, sm);
                 const uint64_t o = flat(gw[0]);
                 w[o] = hf.mul(l, r);
                 assigned[o] = 1;

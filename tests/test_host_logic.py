@@ -38,6 +38,42 @@ def test_no_gpu_means_loud_failure(acx):
 
 
 @pytest.mark.parametrize("fname", ["bn254", "bls12_381"])
+def test_nested_scalar_multiplications_in_canonical_rows(acx, fname):
+    """The host keeps gate-list scalars and row values CANONICAL (no Montgomery conversion in or out); a product of two
+    coefficients -- ScalarMul nodes nested, or a ConstGate under a ScalarMul -- is the one place it multiplies
+    (HostCircuit::cmul), and the host fold works on its own Montgomery copy.  Mul gates whose sides are affine trees of depth
+    up to 6 (ScalarMul nested up to six deep, affineCircuitToAffineMap src/Circuit/Affine.hs:90-105): rows against the
+    oracle's gateToGenQAP, witness against its generateAssignment."""
+    p = (R.BN254 if fname == "bn254" else R.BLS12_381).p
+
+    def depth(a, d=0):
+        if a[0] == "smul":
+            return depth(a[2], d + 1)
+        return max(depth(a[1], d), depth(a[2], d)) if a[0] == "add" else d
+
+    nested = 0
+    for seed in range(40):
+        rnd = random.Random(9000 + seed)
+        nv = rnd.randrange(1, 5)
+        gates, mids = [], []
+        for k in range(rnd.randrange(1, 8)):
+            sides = [H.arb_affine_with_mids(rnd, p, nv, mids, rnd.randrange(0, 7)) for _ in range(2)]
+            nested += sum(depth(a) >= 2 for a in sides)
+            gates.append(R.Mul(sides[0], sides[1], R.IntermediateWire(k)))
+            mids.append(k)
+        circ = H.to_acx_circuit(acx, gates).marshal(fname)
+        dims = H.circuit_dims(gates)
+        n, m, want = H.gen_qap_to_csr(R.arith_circuit_to_gen_qap(R.fresh_roots(gates, 1), gates, p), dims, p)
+        got = circ.rows()
+        for k in range(3):
+            assert H.csr_equal(got[k], want[k]), f"seed {seed} matrix {k}"
+        vals = [rnd.randrange(p) for _ in range(nv)]
+        w, _ = circ.eval(acx.ints_to_fr(vals))
+        assert acx.fr_to_ints(w) == H.qapset_to_flat(R.generate_assignment(gates, dict(enumerate(vals)), p), dims, p), f"seed {seed}"
+    assert nested > 50          # the generator did produce nested products
+
+
+@pytest.mark.parametrize("fname", ["bn254", "bls12_381"])
 @pytest.mark.parametrize("seed", range(5))
 def test_rows_and_witness_match_reference_restatement(acx, fname, seed):
     """arithCircuitToGenQAP rows + generateAssignment: product host code == literal oracle."""
