@@ -237,6 +237,12 @@ struct acx_r1cs {
     uint32_t n_ev_equal = 0;
     bool ev_defer_magic = false;
     bool has_csc = false;
+    // Device memory of a loaded system in TWO allocations (hipMalloc synchronises the device and costs ~7 us: 22 of them and
+    // seven stream waits were most of acx_circuit_to_r1cs on a 2^10-gate circuit): `slab` holds M[k].{ptr, idx, val}, d_w and
+    // d_hscale; `sell_slab` holds perm, long_rows and sell_{ofs, tail, val}[k].  The members point into them and are not freed
+    // one by one (free_r1cs_device).
+    void* slab = nullptr;
+    void* sell_slab = nullptr;
     uint4* d_w = nullptr;  // the witness acx_r1cs_eval leaves resident (m elements); acx_naive_h uses it as scratch
     uint4* d_w_canon = nullptr;                      // conversion target of acx_r1cs_eval's witness download (first use; hipMalloc / hipFree synchronise the device)
     bool resident_valid = false;                     // d_w holds a witness produced by acx_r1cs_eval
@@ -1007,6 +1013,10 @@ int build_sell(acx_r1cs* r, const uint32_t* const rowptr[3]) {
     if (n == 0) return ACX_OK;
     PhaseTimer pt;
     std::vector<uint32_t> key(n), perm((size_t)n_slices * kSlice, kNoRow), longs, tiers[kRowTiers];
+    std::vector<uint32_t> ofs[3];
+    // declared after the vectors the enqueued copies read, so destroyed before them: no exit of this function, an error return
+    // included, leaves a copy from freed host memory in flight
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{cur_stream(c)};
     // Row classes: (lenA, lenB, lenC) with every length <= kSellMaxLen, or "long".  Few classes, so the stable sort of a
     // window is a counting sort (a comparison sort of 2^20 rows cost 32 ms of a 110 ms load).
     constexpr uint32_t kLenRadix = kSellMaxLen + 1, kLongClass = kLenRadix * kLenRadix * kLenRadix;
@@ -1034,50 +1044,67 @@ int build_sell(acx_r1cs* r, const uint32_t* const rowptr[3]) {
             perm[ws + start[key[i]]++] = key[i] == kLongClass ? kNoRow : (uint32_t)i;
     }
     pt.mark("  sell: keys + window sorts");
-    HIP_TRY(hipMalloc((void**)&r->perm, perm.size() * 4));
-    HIP_TRY(hipMemcpyAsync(r->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
     r->n_long = (uint32_t)longs.size();
-    if (!longs.empty()) {
-        HIP_TRY(hipMalloc((void**)&r->long_rows, longs.size() * 4));
-        HIP_TRY(hipMemcpyAsync(r->long_rows, longs.data(), longs.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
-    }
-    std::vector<uint32_t> ofs(n_slices + 1);
+    uint64_t slots[3];
     for (int k = 0; k < 3; ++k) {
-        ofs[0] = 0;
+        ofs[k].resize(n_slices + 1);
+        ofs[k][0] = 0;
         for (uint32_t s = 0; s < n_slices; ++s) {
             uint32_t mx = 0;
             for (int l = 0; l < kSlice; ++l) {
                 const uint32_t row = perm[(size_t)s * kSlice + l];
                 if (row != kNoRow) mx = std::max(mx, rowptr[k][row + 1] - rowptr[k][row]);
             }
-            ofs[s + 1] = ofs[s] + mx;
+            ofs[k][s + 1] = ofs[k][s] + mx;
         }
-        const uint64_t slots = ofs[n_slices];
-        pt.mark("  sell: slice offsets");
-        HIP_TRY(hipMalloc((void**)&r->sell_ofs[k], ofs.size() * 4));
-        HIP_TRY(hipMalloc((void**)&r->sell_tail[k], std::max<uint64_t>(slots, 1) * kSlice * 8));
-        const bool small = (r->small >> k) & 1u;
-        if (!small) HIP_TRY(hipMalloc((void**)&r->sell_val[k], std::max<uint64_t>(slots, 1) * kSlice * 32));
-        HIP_TRY(hipMemcpyAsync(r->sell_ofs[k], ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
-        HIP_TRY(hipStreamSynchronize(cur_stream(c)));   // ofs is reused by the next matrix
+        slots[k] = ofs[k][n_slices];
+    }
+    pt.mark("  sell: slice offsets");
+    {   // one allocation for everything the SELL form holds
+        size_t off = 0, o_ofs[3], o_tail[3], o_val[3];
+        const size_t o_perm = off; off += align256(perm.size() * 4);
+        const size_t o_long = off; off += align256(std::max<size_t>(longs.size(), 1) * 4);
+        for (int k = 0; k < 3; ++k) {
+            o_ofs[k] = off; off += align256(ofs[k].size() * 4);
+            o_tail[k] = off; off += align256(std::max<uint64_t>(slots[k], 1) * kSlice * 8);
+            o_val[k] = off;
+            if (!((r->small >> k) & 1u)) off += align256(std::max<uint64_t>(slots[k], 1) * kSlice * 32);
+        }
+        if (hipMalloc(&r->sell_slab, off) != hipSuccess) { (void)hipGetLastError(); r->sell_slab = nullptr; return fail(ACX_ERR_OOM, "device allocation failed"); }
+        uint8_t* base = static_cast<uint8_t*>(r->sell_slab);
+        r->perm = (u32*)(base + o_perm);
+        if (!longs.empty()) r->long_rows = (u32*)(base + o_long);
+        for (int k = 0; k < 3; ++k) {
+            r->sell_ofs[k] = (u32*)(base + o_ofs[k]);
+            r->sell_tail[k] = (uint2*)(base + o_tail[k]);
+            if (!((r->small >> k) & 1u)) r->sell_val[k] = (uint4*)(base + o_val[k]);
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(r->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
+    if (!longs.empty()) HIP_TRY(hipMemcpyAsync(r->long_rows, longs.data(), longs.size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
+    // the device's check of the small-coefficient classification: one flag for the three matrices, fetched after the last launch
+    uint32_t* d_bad = nullptr;
+    if (r->small) {
+        d_bad = cur_err(c) + 1;                      // second pad word of the call's result slot (the first is the canonicity flag)
+        HIP_TRY(hipMemsetAsync(d_bad, 0, 4, cur_stream(c)));
+    }
+    for (int k = 0; k < 3; ++k) {
+        HIP_TRY(hipMemcpyAsync(r->sell_ofs[k], ofs[k].data(), ofs[k].size() * 4, hipMemcpyHostToDevice, cur_stream(c)));
         const CsrDev M{r->M[k].ptr, r->M[k].idx, r->M[k].val};
-        if (small) {
-            HIP_TRY(hipMemsetAsync(cur_err(c), 0, 4, cur_stream(c)));
+        if ((r->small >> k) & 1u) {
             DISPATCH_FIELD(c, hipLaunchKernelGGL((k_build_sell_small<F>), dim3((n_slices + 3) / 4), dim3(kBlock), 0, cur_stream(c), M,
-                                                 (const u32*)r->perm, (const u32*)r->sell_ofs[k], n_slices, r->sell_tail[k], cur_err(c)));
-            HIP_TRY(hipGetLastError());
-            uint32_t bad = 0;
-            HIP_TRY(hipMemcpyAsync(&bad, cur_err(c), 4, hipMemcpyDeviceToHost, cur_stream(c)));
-            HIP_TRY(hipStreamSynchronize(cur_stream(c)));
-            if (bad) return fail(ACX_ERR_HIP, "small-coefficient classification disagrees with the device");
+                                                 (const u32*)r->perm, (const u32*)r->sell_ofs[k], n_slices, r->sell_tail[k], d_bad));
         } else {
             hipLaunchKernelGGL(k_build_sell, dim3((n_slices + 3) / 4), dim3(kBlock), 0, cur_stream(c), M, (const u32*)r->perm,
                                (const u32*)r->sell_ofs[k], n_slices, r->sell_tail[k], r->sell_val[k]);
-            HIP_TRY(hipGetLastError());
         }
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipStreamSynchronize(cur_stream(c)));
+    uint32_t bad = 0;
+    if (d_bad) HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, cur_stream(c)));
+    HIP_TRY(hipStreamSynchronize(cur_stream(c)));           // perm / longs / ofs (and the caller's matrices) are read by copies until here
     pt.mark("  sell: device build");
+    if (bad) return fail(ACX_ERR_HIP, "small-coefficient classification disagrees with the device");
     return ACX_OK;
 }
 
@@ -1146,21 +1173,14 @@ int normalise_csr(const HostField& hf, uint64_t n, uint64_t m, const acx_csr* in
     return ACX_OK;
 }
 
-int upload_matrix(acx_ctx* c, const uint32_t* ptr, size_t n_ptr, const uint32_t* idx, size_t nnz,
-                  const acx_fr* val, bool convert, DevMatrix& out) {
+// Enqueue the upload of one CSR matrix into buffers the caller carved out of the system's slab (out.ptr / idx / val set), values
+// converted to dev format in place.  No wait: a non-canonical value raises the flag of the call's result slot (begin_call /
+// end_call_fetch), and the host arrays must stay alive until the caller has synchronised the stream.
+int upload_matrix_async(acx_ctx* c, const uint32_t* ptr, size_t n_ptr, const uint32_t* idx, size_t nnz, const acx_fr* val, DevMatrix& out) {
     out.nnz = nnz;
-    HIP_TRY(hipMalloc((void**)&out.ptr, n_ptr * 4));
-    HIP_TRY(hipMalloc((void**)&out.idx, std::max<size_t>(nnz, 1) * 4));
-    HIP_TRY(hipMalloc((void**)&out.val, std::max<size_t>(nnz, 1) * 32));
     HIP_TRY(hipMemcpyAsync(out.ptr, ptr, n_ptr * 4, hipMemcpyHostToDevice, cur_stream(c)));
     if (nnz) HIP_TRY(hipMemcpyAsync(out.idx, idx, nnz * 4, hipMemcpyHostToDevice, cur_stream(c)));
-    if (convert) {
-        ACX_TRY(upload_elements(c, val, nnz, out.val));
-    } else {
-        if (nnz) HIP_TRY(hipMemcpyAsync(out.val, val, nnz * 32, hipMemcpyHostToDevice, cur_stream(c)));
-        HIP_TRY(hipStreamSynchronize(cur_stream(c)));
-    }
-    return ACX_OK;
+    return upload_elements_async(c, val, nnz, out.val);
 }
 
 void free_matrix(DevMatrix& mtx) {
@@ -1172,6 +1192,18 @@ void free_matrix(DevMatrix& mtx) {
 }
 
 void free_r1cs_device(acx_r1cs* r) {
+    if (r->slab) {                                   // the members below are views of the two slabs
+        (void)hipFree(r->slab);
+        r->slab = nullptr;
+        for (int k = 0; k < 3; ++k) { r->M[k].ptr = nullptr; r->M[k].idx = nullptr; r->M[k].val = nullptr; }
+        r->d_w = nullptr; r->d_hscale = nullptr;
+    }
+    if (r->sell_slab) {
+        (void)hipFree(r->sell_slab);
+        r->sell_slab = nullptr;
+        for (int k = 0; k < 3; ++k) { r->sell_ofs[k] = nullptr; r->sell_tail[k] = nullptr; r->sell_val[k] = nullptr; }
+        r->perm = nullptr; r->long_rows = nullptr;
+    }
     for (int k = 0; k < 3; ++k) {
         free_matrix(r->M[k]);
         free_matrix(r->T[k]);
@@ -1196,7 +1228,7 @@ void free_r1cs_device(acx_r1cs* r) {
     if (r->d_w) (void)hipFree(r->d_w);
     if (r->qh) (void)hipFree(r->qh);
     if (r->d_hscale) (void)hipFree(r->d_hscale);
-    r->perm = nullptr; r->long_rows = nullptr; r->d_w = nullptr; r->qh = nullptr;
+    r->perm = nullptr; r->long_rows = nullptr; r->d_w = nullptr; r->qh = nullptr; r->d_hscale = nullptr;
 }
 
 int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* const mats[3], acx_r1cs** out) {
@@ -1218,6 +1250,9 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* const ma
         std::vector<uint32_t> own_rowptr[3], own_col[3];
         std::vector<acx_fr> own_val[3];
         const uint32_t* rowptrs[3] = {nullptr, nullptr, nullptr};
+        const uint32_t* cols[3] = {nullptr, nullptr, nullptr};
+        const acx_fr* vals[3] = {nullptr, nullptr, nullptr};
+        uint64_t nnzs[3] = {0, 0, 0};
         for (int k = 0; k < 3 && rc == ACX_OK; ++k) {
             const acx_csr* in = mats[k];
             if (!in || !in->rowptr) { rc = fail(ACX_ERR_INVALID_ARG, "null CSR"); break; }
@@ -1264,24 +1299,50 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* const ma
                 if (small) r->small |= 1u << k;
             }
             pt.mark("classify");
-            if (rc == ACX_OK) rc = upload_matrix(ctx, rowptr, n + 1, col, nnz, val, true, r->M[k]);
-            pt.mark("upload_matrix");
+            cols[k] = col; vals[k] = val; nnzs[k] = nnz;
         }
-        if (rc == ACX_OK) rc = build_sell(r, rowptrs);
+        // one allocation for the three matrices, the resident witness and the h(x) constants; every upload enqueued without a
+        // wait, ONE canonicity flag for all values (the call's result slot), one stream wait at the end of build_sell
+        const bool with_h = (int)log_n + 1 <= ctx->hf.two_adicity();
+        H256 hpair[2];
+        if (rc == ACX_OK) {
+            size_t off = 0, o_ptr[3], o_idx[3], o_val[3];
+            for (int k = 0; k < 3; ++k) {
+                o_ptr[k] = off; off += align256((n + 1) * 4);
+                o_idx[k] = off; off += align256(std::max<uint64_t>(nnzs[k], 1) * 4);
+                o_val[k] = off; off += align256(std::max<uint64_t>(nnzs[k], 1) * 32);
+            }
+            const size_t o_w = off; off += align256(m * 32);
+            const size_t o_h = off; off += 256;
+            if (hipMalloc(&r->slab, off) != hipSuccess) { (void)hipGetLastError(); r->slab = nullptr; rc = fail(ACX_ERR_OOM, "device allocation failed"); }
+            if (rc == ACX_OK) {
+                uint8_t* base = static_cast<uint8_t*>(r->slab);
+                for (int k = 0; k < 3; ++k) {
+                    r->M[k].ptr = (u32*)(base + o_ptr[k]); r->M[k].idx = (u32*)(base + o_idx[k]); r->M[k].val = (uint4*)(base + o_val[k]);
+                }
+                r->d_w = (uint4*)(base + o_w);
+                rc = begin_call(ctx);
+                for (int k = 0; k < 3 && rc == ACX_OK; ++k) rc = upload_matrix_async(ctx, rowptrs[k], n + 1, cols[k], nnzs[k], vals[k], r->M[k]);
+                if (rc == ACX_OK && with_h) {
+                    // {1/z, -1/z}, z = g^N - 1 (the target polynomial on the coset g<omega>): the factors the h(x) pipeline lets
+                    // ride on the stored dot products.  They depend on N alone; made here so that concurrent callers find them ready.
+                    const HostField& hf = ctx->hf;
+                    const H256 zinv = hf.inv(hf.sub(hf.pow_u64(hf.generator(), 1ull << log_n), hf.one()));
+                    hpair[0] = hf.to_dev_word(zinv); hpair[1] = hf.to_dev_word(hf.sub(hf.zero(), zinv));
+                    r->d_hscale = (uint4*)(base + o_h);
+                    if (hipMemcpyAsync(r->d_hscale, hpair, 64, hipMemcpyHostToDevice, cur_stream(ctx)) != hipSuccess) rc = fail(ACX_ERR_HIP, "h(x) constants");
+                }
+            }
+            pt.mark("upload (enqueued)");
+        }
+        if (rc == ACX_OK) rc = build_sell(r, rowptrs);                     // ends with the stream wait: host arrays are free after it
+        else if (r->slab) (void)hipStreamSynchronize(cur_stream(ctx));    // never leave copies from host arrays in flight
         pt.mark("build_sell");
         if (rc == ACX_OK) {
-            hipError_t e = hipMalloc((void**)&r->d_w, m * 32);
-            if (e != hipSuccess) rc = fail(ACX_ERR_OOM, "witness buffer allocation failed");
-        }
-        if (rc == ACX_OK && (int)log_n + 1 <= ctx->hf.two_adicity()) {
-            // {1/z, -1/z}, z = g^N - 1 (the target polynomial on the coset g<omega>): the factors the h(x) pipeline lets ride
-            // on the stored dot products.  They depend on N alone; made here so that concurrent callers find them ready.
-            const HostField& hf = ctx->hf;
-            const H256 zinv = hf.inv(hf.sub(hf.pow_u64(hf.generator(), 1ull << log_n), hf.one()));
-            const H256 pair[2] = {hf.to_dev_word(zinv), hf.to_dev_word(hf.sub(hf.zero(), zinv))};
-            hipError_t e = hipMalloc((void**)&r->d_hscale, 64);
-            if (e == hipSuccess) e = hipMemcpy(r->d_hscale, pair, 64, hipMemcpyHostToDevice);
-            if (e != hipSuccess) rc = fail(ACX_ERR_HIP, "h(x) constants");
+            CallSlot slot;
+            rc = end_call_fetch(ctx, &slot);
+            if (rc == ACX_OK && hipStreamSynchronize(cur_stream(ctx)) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream");
+            if (rc == ACX_OK && slot.noncanonical) rc = fail(ACX_ERR_NONCANONICAL, "element >= p");
         }
     } catch (const std::bad_alloc&) {
         rc = fail(ACX_ERR_OOM, "host allocation failed");
