@@ -192,7 +192,9 @@ int acx_circuit_rows(const acx_circuit* c, const acx_fr* roots, uint64_t n_roots
  * column; duplicate columns in a row are summed.  Limits: 1 <= m < 2^32 - 1, n < 2^32 - 1, n <= 2^two-adicity
  * of the field (2^28 for BN254 Fr, 2^32 for BLS12-381 Fr), fewer than 2^32 entries per matrix
  * (ACX_ERR_TOO_LARGE otherwise); columns must be < m and values canonical (ACX_ERR_INVALID_ARG /
- * ACX_ERR_NONCANONICAL). */
+ * ACX_ERR_NONCANONICAL).  The structure of all three matrices is checked on the host before any value is
+ * uploaded; canonicity is checked on the device, one flag for the whole load: of a structural defect and a
+ * non-canonical value in the same call the structural defect is the one reported. */
 int acx_r1cs_load(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* A, const acx_csr* B,
                   const acx_csr* C, acx_r1cs** out);
 void acx_r1cs_destroy(acx_r1cs* r);
