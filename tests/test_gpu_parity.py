@@ -60,6 +60,42 @@ def test_field_golden_through_device(request, acx, case):
     assert e.value.status == acx._lib.STATUS["NONCANONICAL"]
 
 
+@pytest.mark.parametrize("field", ["bn254", "bls12_381"])
+def test_load_checks_cover_all_three_matrices_and_leave_the_context_usable(request, acx, field):
+    """acx_r1cs_load enqueues the three matrices without waiting in between and reads ONE canonicity flag at the end
+    (include/acx.h): a value >= p in A, in B or in C alone is refused with ACX_ERR_NONCANONICAL; a column >= m is the host's
+    ACX_ERR_INVALID_ARG and wins over a non-canonical value of the same call; after every refusal the same context loads and
+    verifies a good system (nothing of the failed load is left in flight or allocated twice)."""
+    ctx = _ctx(request, field)
+    s = acx.synth.mulgraph(700, n_in=16, window=64, seed=31, field=field)
+    mats, w = s.rows(), s.witness()
+    n, m = s.circuit.n_rows, s.circuit.m
+    too_big = np.array([2**64 - 1] * 4, dtype=np.uint64)                  # >= p for both fields
+
+    def spoiled(k, bad_col=None):
+        out = [(rp.copy(), col.copy(), val.copy()) for rp, col, val in mats]
+        out[k][2][len(out[k][2]) // 2] = too_big
+        if bad_col is not None:
+            out[bad_col][1][3] = m
+        return out
+
+    def good():
+        r = acx.R1CS.load(ctx, n, m, *mats)
+        assert r.verify(w)[0]
+        r.close()
+
+    good()
+    for k in range(3):
+        with pytest.raises(acx.AcxError) as e:
+            acx.R1CS.load(ctx, n, m, *spoiled(k))
+        assert e.value.status == acx._lib.STATUS["NONCANONICAL"], f"matrix {k}"
+        good()
+    with pytest.raises(acx.AcxError) as e:
+        acx.R1CS.load(ctx, n, m, *spoiled(0, bad_col=2))
+    assert e.value.status == acx._lib.STATUS["INVALID_ARG"]
+    good()
+
+
 @pytest.mark.parametrize("case", G.load("ntt_cases.json"), ids=lambda c: f'{c["field"]}-{c["log_n"]}')
 def test_ntt_golden(request, acx, case):
     ctx = _ctx(request, case["field"])
