@@ -243,6 +243,8 @@ struct acx_r1cs {
     // one by one (free_r1cs_device).
     void* slab = nullptr;
     void* sell_slab = nullptr;
+    void* csc_slab = nullptr;        // T[k].{ptr, idx, colid, val} of a system whose column views were built on the device (build_csc);
+                                     // the column slices of acx_mgpu own their T[k] members one by one (r1cs_column_slice_from_host)
     uint4* d_w = nullptr;  // the witness acx_r1cs_eval leaves resident (m elements); acx_naive_h uses it as scratch
     uint4* d_w_canon = nullptr;                      // conversion target of acx_r1cs_eval's witness download (first use; hipMalloc / hipFree synchronise the device)
     bool resident_valid = false;                     // d_w holds a witness produced by acx_r1cs_eval
@@ -1191,7 +1193,18 @@ void free_matrix(DevMatrix& mtx) {
     mtx = DevMatrix{};
 }
 
+// the column views: the slab when build_csc made them, member by member otherwise
+void free_csc(acx_r1cs* r) {
+    if (r->csc_slab) {
+        (void)hipFree(r->csc_slab);
+        r->csc_slab = nullptr;
+        for (int k = 0; k < 3; ++k) { r->T[k].ptr = nullptr; r->T[k].idx = nullptr; r->T[k].colid = nullptr; r->T[k].val = nullptr; }
+    }
+    for (int k = 0; k < 3; ++k) free_matrix(r->T[k]);
+}
+
 void free_r1cs_device(acx_r1cs* r) {
+    free_csc(r);
     if (r->slab) {                                   // the members below are views of the two slabs
         (void)hipFree(r->slab);
         r->slab = nullptr;
@@ -1206,7 +1219,6 @@ void free_r1cs_device(acx_r1cs* r) {
     }
     for (int k = 0; k < 3; ++k) {
         free_matrix(r->M[k]);
-        free_matrix(r->T[k]);
         if (r->sell_ofs[k]) (void)hipFree(r->sell_ofs[k]);
         if (r->sell_tail[k]) (void)hipFree(r->sell_tail[k]);
         if (r->sell_val[k]) (void)hipFree(r->sell_val[k]);
@@ -1360,33 +1372,41 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* const ma
 static int build_csc(acx_r1cs* r) {
     acx_ctx* c = r->ctx;
     const hipStream_t st = cur_stream(c);
+    // one allocation for the three views and the histogram / cursor scratch (the launches of the three matrices are ordered on
+    // one stream, so they share the scratch), one wait at the end: 18 hipMallocs, 6 hipFrees and 3 waits before
+    size_t off = 0, o_ptr[3], o_idx[3], o_colid[3], o_val[3];
+    for (int k = 0; k < 3; ++k) {
+        const uint64_t e = std::max<uint64_t>(r->M[k].nnz, 1);
+        o_ptr[k] = off; off += align256((r->m + 1) * 4);
+        o_idx[k] = off; off += align256(e * 4);
+        o_colid[k] = off; off += align256(e * 4);
+        o_val[k] = off; off += align256(e * 32);
+    }
+    const size_t o_count = off; off += align256((r->m + 1) * 4);
+    const size_t o_cursor = off; off += align256((r->m + 1) * 4);
+    if (hipMalloc(&r->csc_slab, off) != hipSuccess) { (void)hipGetLastError(); r->csc_slab = nullptr; return fail(ACX_ERR_OOM, "device allocation failed"); }
+    uint8_t* base = static_cast<uint8_t*>(r->csc_slab);
+    u32* count = (u32*)(base + o_count);
+    u32* cursor = (u32*)(base + o_cursor);
     for (int k = 0; k < 3; ++k) {
         const DevMatrix& M = r->M[k];
         DevMatrix& T = r->T[k];
         T.nnz = M.nnz;
-        DevBuf count, cursor;
-        ACX_TRY(count.alloc((r->m + 1) * 4));
-        ACX_TRY(cursor.alloc((r->m + 1) * 4));
-        HIP_TRY(hipMalloc((void**)&T.ptr, (r->m + 1) * 4));
-        HIP_TRY(hipMalloc((void**)&T.idx, std::max<uint64_t>(M.nnz, 1) * 4));
-        HIP_TRY(hipMalloc((void**)&T.colid, std::max<uint64_t>(M.nnz, 1) * 4));
-        HIP_TRY(hipMalloc((void**)&T.val, std::max<uint64_t>(M.nnz, 1) * 32));
-        HIP_TRY(hipMemsetAsync(count.p, 0, (r->m + 1) * 4, st));
-        HIP_TRY(hipMemsetAsync(cursor.p, 0, (r->m + 1) * 4, st));
-        if (M.nnz) hipLaunchKernelGGL(k_col_histogram, dim3(grid_for(c, M.nnz)), dim3(kBlock), 0, st, (const u32*)M.idx, M.nnz, count.as<u32>());
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const u32*)count.as<u32>(), T.ptr, r->m);
+        T.ptr = (u32*)(base + o_ptr[k]); T.idx = (u32*)(base + o_idx[k]); T.colid = (u32*)(base + o_colid[k]); T.val = (uint4*)(base + o_val[k]);
+        HIP_TRY(hipMemsetAsync(count, 0, (r->m + 1) * 4, st));
+        HIP_TRY(hipMemsetAsync(cursor, 0, (r->m + 1) * 4, st));
+        if (M.nnz) hipLaunchKernelGGL(k_col_histogram, dim3(grid_for(c, M.nnz)), dim3(kBlock), 0, st, (const u32*)M.idx, M.nnz, count);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const u32*)count, T.ptr, r->m);
         if (M.nnz) {
             const CsrDev csr{M.ptr, M.idx, M.val};
-            hipLaunchKernelGGL(k_csc_fill, dim3(grid_for(c, r->n)), dim3(kBlock), 0, st, csr, r->n, (const u32*)T.ptr, cursor.as<u32>(),
+            hipLaunchKernelGGL(k_csc_fill, dim3(grid_for(c, r->n)), dim3(kBlock), 0, st, csr, r->n, (const u32*)T.ptr, cursor,
                                T.idx, T.colid, T.val);
         }
-        HIP_TRY(hipGetLastError());                // before the host copy of colptr is consumed
-        T.h_ptr.resize(r->m + 1);
-        const hipError_t e1 = hipMemcpyAsync(T.h_ptr.data(), T.ptr, (r->m + 1) * 4, hipMemcpyDeviceToHost, st);
-        const hipError_t e2 = hipStreamSynchronize(st);       // count / cursor go out of scope; other lanes may use the CSC from here on
-        HIP_TRY(e1);
-        HIP_TRY(e2);
+        HIP_TRY(hipGetLastError());
+        T.h_ptr.resize(r->m + 1);                  // host copy of colptr: qap_columns_core sorts a batch into sparse and dense columns with it
+        HIP_TRY(hipMemcpyAsync(T.h_ptr.data(), T.ptr, (r->m + 1) * 4, hipMemcpyDeviceToHost, st));
     }
+    HIP_TRY(hipStreamSynchronize(st));             // the host copies are complete; other lanes may use the views from here on
     return ACX_OK;
 }
 
@@ -1399,7 +1419,7 @@ int ensure_csc(acx_r1cs* r) {
     const int rc = build_csc(r);
     if (rc != ACX_OK) {
         (void)hipStreamSynchronize(cur_stream(c));
-        for (int k = 0; k < 3; ++k) free_matrix(r->T[k]);
+        free_csc(r);
         return rc;
     }
     r->has_csc = true;
