@@ -272,6 +272,17 @@ struct acx_naive {          // createPolynomials state for arbitrary distinct ro
 
 namespace {
 
+// Waits for a stream when it goes out of scope.  Declare it AFTER the host objects that enqueued copies read from (locals are
+// destroyed in reverse order): then no exit of the function, an error return included, leaves a copy from freed host memory in
+// flight.  On the normal path the function has waited already and this is a no-op of ~2 us.
+struct StreamDrain {
+    hipStream_t s;
+    explicit StreamDrain(hipStream_t st) : s(st) {}
+    ~StreamDrain() { (void)hipStreamSynchronize(s); }
+    StreamDrain(const StreamDrain&) = delete;
+    StreamDrain& operator=(const StreamDrain&) = delete;
+};
+
 struct DevBuf {  // RAII scratch
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -1016,9 +1027,7 @@ int build_sell(acx_r1cs* r, const uint32_t* const rowptr[3]) {
     PhaseTimer pt;
     std::vector<uint32_t> key(n), perm((size_t)n_slices * kSlice, kNoRow), longs, tiers[kRowTiers];
     std::vector<uint32_t> ofs[3];
-    // declared after the vectors the enqueued copies read, so destroyed before them: no exit of this function, an error return
-    // included, leaves a copy from freed host memory in flight
-    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{cur_stream(c)};
+    StreamDrain drain(cur_stream(c));          // after the vectors above: they outlive every copy enqueued from them
     // Row classes: (lenA, lenB, lenC) with every length <= kSellMaxLen, or "long".  Few classes, so the stable sort of a
     // window is a counting sort (a comparison sort of 2^20 rows cost 32 ms of a 110 ms load).
     constexpr uint32_t kLenRadix = kSellMaxLen + 1, kLongClass = kLenRadix * kLenRadix * kLenRadix;
@@ -1891,6 +1900,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
     std::memset(w0.data(), 0, w0.size() * 32);
     w0[0].b[0] = 1;
     for (uint64_t i = 0; i < n_use; ++i) if (!present || present[i]) w0[1 + i] = inputs[i];
+    StreamDrain drain(cur_stream(c));          // after w0: it outlives the copy enqueued from it on every exit
     r->resident_valid = false;
     // no host round trip before the levels: the canonicity flag of the inputs comes back with the call's result slot
     ACX_TRY(begin_call(c));
