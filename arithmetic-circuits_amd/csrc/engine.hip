@@ -1844,6 +1844,7 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
         const size_t off_res = align256(chunk_max * wbytes), off_desc = align256(off_res + chunk_max * 16);
         uint8_t* base = nullptr;
         ACX_TRY(lane_reserve(c, off_desc + chunk_max * sizeof(SellSystem), &base));
+        StreamDrain drain(cur_stream(c));          // after desc / res: they outlive the copies enqueued from and into them on every exit
         uint4* d_w = (uint4*)base;
         unsigned long long* d_res = (unsigned long long*)(base + off_res);
         SellSystem* d_desc = (SellSystem*)(base + off_desc);

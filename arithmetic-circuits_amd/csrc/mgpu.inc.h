@@ -1373,6 +1373,13 @@ int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* mr, uint32_t slot0, uint32_t count, ui
         DevGuard dg;
         const uint32_t W = mg->W;
         std::vector<unsigned long long> host(2 * count), init(2 * count);
+        std::vector<std::vector<unsigned long long>> per;
+        // after the vectors the copies below read and write: every exit, an error return between the enqueues and the waits
+        // included, first waits for all shards' streams
+        struct DrainAll {
+            acx_mgpu* mg;
+            ~DrainAll() { for (uint32_t s = 0; s < mg->W; ++s) { (void)hipSetDevice(mg->sh[s].device); (void)hipStreamSynchronize(mg->sh[s].ctx->stream); } }
+        } drain{mg};
         for (uint32_t i = 0; i < count; ++i) { init[2 * i] = 0; init[2 * i + 1] = ~0ull; }
         for (uint32_t i = 0; i < count; ++i) n_bad[i] = 0;
         if (mg->rccl) {
@@ -1399,7 +1406,7 @@ int acx_mgpu_r1cs_verdicts(acx_mgpu_r1cs* mr, uint32_t slot0, uint32_t count, ui
             for (uint32_t i = 0; i < count; ++i) n_bad[i] = host[2 * i];
             return ACX_OK;
         }
-        std::vector<std::vector<unsigned long long>> per(W, std::vector<unsigned long long>(2 * count));
+        per.assign(W, std::vector<unsigned long long>(2 * count));
         for (uint32_t s = 0; s < W; ++s) {
             MgShard& S = mg->sh[s];
             HIP_TRY(hipSetDevice(S.device));
