@@ -19,7 +19,10 @@
  *     points that block on the GPU (acx_r1cs_verify, acx_r1cs_residuals, acx_qap_h, acx_qap_columns, acx_ntt) run
  *     concurrently for up to four callers per context (one HIP stream + scratch arena each): `safe` foreign
  *     calls from several Haskell capabilities overlap (test/Test/Circuit/Arithmetic.hs:209 maps verifyAssignment
- *     over many inputs).  The device-pointer entry points share the single stream acx_ctx_stream() returns.
+ *     over many inputs).  Four callers with page-locked witness buffers (hipHostRegister / pinned allocations) reach
+ *     1.7 - 1.9 times one caller's rate on every host measured; with pageable buffers the HIP runtime stages the copies
+ *     itself and the same four callers gave between 0.8 and 1.9 times, depending on the host (profiles/r04_bench_line*.json,
+ *     `e2e`).  The device-pointer entry points share the single stream acx_ctx_stream() returns.
  *   - There is NO CPU fallback: without a usable gfx950 device acx_ctx_create fails with
  *     ACX_ERR_NO_DEVICE and nothing else can be called.
  */
