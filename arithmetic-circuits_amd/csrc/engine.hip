@@ -103,6 +103,7 @@ struct acx_ctx {
         hipStream_t stream = nullptr;
         unsigned long long* d_result = nullptr;
         uint32_t* d_err = nullptr;
+        void* h_slot = nullptr;                // page-locked host copy of the call's result slot (cur_hslot)
         void* arena = nullptr;
         size_t arena_bytes = 0;
         uint4* ntt_scratch = nullptr;
@@ -155,6 +156,7 @@ struct acx_ctx {
     uint64_t coset_clock = 0;
     unsigned long long* d_result = nullptr;                // {n_bad, first_bad}
     uint32_t* d_err = nullptr;
+    void* h_slot = nullptr;                                // page-locked host copy of the result slot, calls without a lane (under mu)
     int n_cu = 256;
 };
 
@@ -165,6 +167,7 @@ static thread_local acx_ctx::Lane* t_lane = nullptr;
 static inline hipStream_t cur_stream(const acx_ctx* c) { return t_lane ? t_lane->stream : c->stream; }
 static inline unsigned long long* cur_result(const acx_ctx* c) { return t_lane ? t_lane->d_result : c->d_result; }
 static inline uint32_t* cur_err(const acx_ctx* c) { return t_lane ? t_lane->d_err : c->d_err; }
+static inline void* cur_hslot_raw(const acx_ctx* c) { return t_lane ? t_lane->h_slot : c->h_slot; }
 
 struct LaneGuard {
     acx_ctx::Lane* lane = nullptr;
@@ -379,6 +382,11 @@ int upload_elements_async(acx_ctx* c, const acx_fr* host, uint64_t count, uint4*
     HIP_TRY(hipMemcpyAsync(d_out, host, count * 32, hipMemcpyHostToDevice, cur_stream(c)));
     return launch_convert(c, true, d_out, d_out, count, cur_err(c));
 }
+// Where a call's result slot lands on the host: page-locked memory of the lane (of the context for calls under ctx->mu).  The
+// 32-byte copy back + wait that ends every blocking call takes 16 us into page-locked memory and 26 us into a stack variable
+// (tools/microbench/pcie_rates.hip: the runtime stages pageable destinations); the lane / the context lock is held until the
+// call has read it.
+static inline CallSlot& cur_hslot(const acx_ctx* c) { return *static_cast<CallSlot*>(cur_hslot_raw(c)); }
 inline int end_call_fetch(acx_ctx* c, CallSlot* host) {      // the caller synchronises the stream afterwards
     HIP_TRY(hipMemcpyAsync(host, cur_result(c), sizeof(CallSlot), hipMemcpyDeviceToHost, cur_stream(c)));
     return ACX_OK;
@@ -1360,7 +1368,7 @@ int r1cs_from_host(acx_ctx* ctx, uint64_t n, uint64_t m, const acx_csr* const ma
         else if (r->slab) (void)hipStreamSynchronize(cur_stream(ctx));    // never leave copies from host arrays in flight
         pt.mark("build_sell");
         if (rc == ACX_OK) {
-            CallSlot slot;
+            CallSlot& slot = cur_hslot(ctx);
             rc = end_call_fetch(ctx, &slot);
             if (rc == ACX_OK && hipStreamSynchronize(cur_stream(ctx)) != hipSuccess) rc = fail(ACX_ERR_HIP, "stream");
             if (rc == ACX_OK && slot.noncanonical) rc = fail(ACX_ERR_NONCANONICAL, "element >= p");
@@ -1518,11 +1526,12 @@ int acx_ctx_create(int field, int device_id, acx_ctx** out) {
     c->ntt = ntt_cfg_from_env();
     if (const char* e = std::getenv("ACX_R1CS_SMALL")) c->small_coeff = std::atoi(e) != 0;   // development A/B switch
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void**)&c->d_result, 32) == hipSuccess;      // {n_bad, first_bad, canonicity flag, pad}: one copy in, one out
+              hipMalloc((void**)&c->d_result, 32) == hipSuccess &&    // {n_bad, first_bad, canonicity flag, pad}: one copy in, one out
+              hipHostMalloc(&c->h_slot, 64) == hipSuccess;
     if (ok) c->d_err = (uint32_t*)(c->d_result + 2);
     for (auto& ln : c->lanes)
         ok = ok && hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess &&
-             hipMalloc((void**)&ln.d_result, 32) == hipSuccess;
+             hipMalloc((void**)&ln.d_result, 32) == hipSuccess && hipHostMalloc(&ln.h_slot, 64) == hipSuccess;
     if (ok) for (auto& ln : c->lanes) ln.d_err = (uint32_t*)(ln.d_result + 2);
     if (!ok) {
         acx_ctx_destroy(c);
@@ -1546,9 +1555,11 @@ void acx_ctx_destroy(acx_ctx* c) {
     for (auto& e : c->cosets) { if (e.lo) (void)hipFree(e.lo); if (e.hi) (void)hipFree(e.hi); }
     c->cosets.clear();
     if (c->d_result) (void)hipFree(c->d_result);                   // d_err lives inside it
+    if (c->h_slot) (void)hipHostFree(c->h_slot);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto& ln : c->lanes) {
         if (ln.d_result) (void)hipFree(ln.d_result);
+        if (ln.h_slot) (void)hipHostFree(ln.h_slot);
         if (ln.arena) (void)hipFree(ln.arena);
         if (ln.ntt_scratch) (void)hipFree(ln.ntt_scratch);
         for (auto& e : ln.ev) if (e) (void)hipEventDestroy(e);
@@ -1800,7 +1811,7 @@ static int verify_common(acx_r1cs* r, const acx_fr* witness, uint4* d_w, uint64_
     ACX_TRY(begin_call(c));
     ACX_TRY(upload_elements_async(c, witness, r->m, d_w));
     ACX_TRY(launch_residual(r, d_w, 0, cur_result(c), d_res, d_dots, dots_stride));
-    CallSlot slot;
+    CallSlot& slot = cur_hslot(c);
     ACX_TRY(end_call_fetch(c, &slot));
     HIP_TRY(hipStreamSynchronize(cur_stream(c)));
     if (slot.noncanonical) return fail(ACX_ERR_NONCANONICAL, "element >= p");
@@ -1864,7 +1875,7 @@ int acx_r1cs_verify_many(acx_r1cs* r, uint64_t count, const acx_fr* witnesses, u
                 HIP_TRY(hipGetLastError());
             }
             if (r->n_long) ACX_TRY(launch_long_rows(r, nullptr, ResidualOut{}, d_desc, (uint32_t)k));   // one launch per tier for all witnesses
-            CallSlot slot;
+            CallSlot& slot = cur_hslot(c);
             HIP_TRY(hipMemcpyAsync(res.data(), d_res, k * 16, hipMemcpyDeviceToHost, cur_stream(c)));
             ACX_TRY(end_call_fetch(c, &slot));
             HIP_TRY(hipStreamSynchronize(cur_stream(c)));
@@ -1944,7 +1955,7 @@ int acx_r1cs_eval(acx_r1cs* r, const acx_fr* inputs, const uint8_t* present, uin
         DISPATCH_FIELD(c, hipLaunchKernelGGL((k_eval_magic<F>), dim3((r->n_ev_equal + kSlice - 1) / kSlice), dim3(kSlice), 0, cur_stream(c),
                                              (const u32*)r->ev_equal, r->n_ev_equal, (const u32*)r->ev_wire_ofs, (const u32*)r->ev_wires, r->d_w));
     HIP_TRY(hipGetLastError());
-    CallSlot slot;
+    CallSlot& slot = cur_hslot(c);
     if (witness) {
         if (!r->d_w_canon) HIP_TRY(hipMalloc((void**)&r->d_w_canon, r->m * 32));
         ACX_TRY(launch_convert(c, false, r->d_w, r->d_w_canon, r->m, nullptr));
@@ -2111,7 +2122,7 @@ int acx_qap_h(acx_r1cs* r, const acx_fr* witness, const acx_fr* delta, acx_fr* o
     ACX_TRY(begin_call(c));
     ACX_TRY(upload_elements_async(c, witness, r->m, d_wit));
     ACX_TRY(qap_h_dev_locked(r, d_wit, delta ? dl : nullptr, d_h, cur_result(c), (uint4*)(base + wb + hb)));
-    CallSlot slot;
+    CallSlot& slot = cur_hslot(c);
     ACX_TRY(end_call_fetch(c, &slot));
     ACX_TRY(download_elements(c, d_h, N + 1, out_h, d_h + 2 * (N + 1)));                 // synchronises the stream
     if (slot.noncanonical) return fail(ACX_ERR_NONCANONICAL, "element >= p");

@@ -2,6 +2,7 @@
 // pinned, and the staged variant (DMA into pinned double buffers + worker-thread memcpy into the pageable destination).
 // hipcc --offload-arch=gfx950 -O3 -pthread -o _build/pcie_rates pcie_rates.hip
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +17,39 @@ static void par_copy(char* dst, const char* src, size_t n, unsigned T) {
     for (unsigned t = 0; t < T; ++t) th.emplace_back([=] { size_t a = n * t / T, b = n * (t + 1) / T; memcpy(dst + a, src + a, b - a); });
     for (auto& x : th) x.join();
 }
+__global__ void k_touch(unsigned long long* p) { if (threadIdx.x == 0) p[0] += 1; }
+
+// The round trip of one blocking ABI call around its kernels: a 32-byte slot copied in, a kernel, the slot copied out, one
+// stream wait -- with the host side of the slot on the stack (pageable: what libacx does) and in page-locked memory.
+static int slot_round_trips() {
+    unsigned long long* d; CK(hipMalloc(&d, 32)); CK(hipMemset(d, 0, 32));
+    unsigned long long* pin; CK(hipHostMalloc(&pin, 64));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    const int reps = 3000;
+    for (int mode = 0; mode < 4; ++mode) {
+        unsigned long long stack_in[4] = {0, ~0ull, 0, 0}, stack_out[4];
+        unsigned long long* in = (mode & 1) ? pin : stack_in;
+        unsigned long long* out = (mode & 2) ? pin + 4 : stack_out;
+        in[0] = 0; in[1] = ~0ull; in[2] = 0; in[3] = 0;
+        double best = 1e9;
+        for (int round = 0; round < 3; ++round) {
+            const double t0 = now();
+            for (int i = 0; i < reps; ++i) {
+                CK(hipMemcpyAsync(d, in, 32, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, s, d);
+                CK(hipMemcpyAsync(out, d, 32, hipMemcpyDeviceToHost, s));
+                CK(hipStreamSynchronize(s));
+            }
+            best = std::min(best, (now() - t0) / reps);
+        }
+        printf("slot round trip (32 B in, kernel, 32 B out, wait): in %-8s out %-8s %6.1f us\n", (mode & 1) ? "pinned" : "pageable",
+               (mode & 2) ? "pinned" : "pageable", best * 1e6);
+    }
+    return 0;
+}
+
 int main() {
+    if (slot_round_trips()) return 1;
     const size_t B = 512ull << 20, CH = 16ull << 20;
     char* d; CK(hipMalloc(&d, B)); CK(hipMemset(d, 1, B));
     char* pin; CK(hipHostMalloc(&pin, B));
