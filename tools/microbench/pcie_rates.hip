@@ -45,6 +45,27 @@ static int slot_round_trips() {
         printf("slot round trip (32 B in, kernel, 32 B out, wait): in %-8s out %-8s %6.1f us\n", (mode & 1) ? "pinned" : "pageable",
                (mode & 2) ? "pinned" : "pageable", best * 1e6);
     }
+    // a small result download into the caller's pageable buffer: direct, against a copy into page-locked staging + memcpy
+    char* dbuf; CK(hipMalloc(&dbuf, 4 << 20)); CK(hipMemset(dbuf, 3, 4 << 20));
+    char* stage; CK(hipHostMalloc(&stage, 4 << 20));
+    std::vector<char> user(4 << 20, 1);
+    for (size_t bytes : {(size_t)32 << 10, (size_t)256 << 10, (size_t)2 << 20}) {
+        double best[2] = {1e9, 1e9};
+        for (int round = 0; round < 3; ++round)
+            for (int staged = 0; staged < 2; ++staged) {
+                const int n = 500;
+                const double t0 = now();
+                for (int i = 0; i < n; ++i) {
+                    hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, s, d);
+                    CK(hipMemcpyAsync(staged ? stage : user.data(), dbuf, bytes, hipMemcpyDeviceToHost, s));
+                    CK(hipStreamSynchronize(s));
+                    if (staged) memcpy(user.data(), stage, bytes);
+                }
+                best[staged] = std::min(best[staged], (now() - t0) / n);
+            }
+        printf("download of %4zu KB after a kernel, pageable destination: direct %6.1f us, staged through page-locked memory %6.1f us\n",
+               bytes >> 10, best[0] * 1e6, best[1] * 1e6);
+    }
     return 0;
 }
 
