@@ -321,7 +321,7 @@ def _from_dev(ctx, t, count):
 
 def _valu_rate():
     """measured integer-multiplier issue rate (tools/microbench/valu_rates.hip -> profiles/r01_valu_rates.txt), via the committed table"""
-    tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
     return tr["valu_rate"]["simds"], tr["valu_rate"]["wave_insts_per_s_per_simd"], tr
 
 
@@ -334,7 +334,7 @@ def _valu_issue(key, count_field, us, workload, live_count=None):
         if live_count is None:
             if tr[key]["workload"] != workload:
                 return None
-            count, measured, src = tr[key][count_field], False, "profiles/r03_traffic.json, profiles/r01_valu_rates.txt"
+            count, measured, src = tr[key][count_field], False, "profiles/r04_traffic.json, profiles/r01_valu_rates.txt"
         else:
             count, measured, src = live_count, True, "SQ_INSTS_VALU from a rocprofv3 --pmc pass of this run; issue rate from profiles/r01_valu_rates.txt"
         bound_us = count / simds / rate * 1e6
@@ -972,7 +972,7 @@ def main():
     ap.add_argument("--dist-logn", type=int, default=24, help="size of the distributed NTT / h(x) job timed when N > 1 or --force-dist")
     ap.add_argument("--no-dist-pipeline", action="store_true", help="skip the distributed NTT / h(x) measurements of a multi-rank run")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE pass (roofline.traffic then comes from profiles/r03_traffic.json, flagged)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE pass (roofline.traffic then comes from profiles/r04_traffic.json, flagged)")
     ap.add_argument("--only-steps", action="store_true", help="internal: nothing but the batched launches (the child of the PMC pass)")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--only-ntt", action="store_true", help="internal: nothing but 40 single 2^20-point transforms (the child of the NTT counter pass)")
@@ -1287,7 +1287,7 @@ def secondary_objects(a, out, ctx, stream, world, use_dist, device, systems, wit
     live_valu = guard("pmc_valu", measure_counter_live, a, "SQ_INSTS_VALU") if live is not None else None      # second pass, its own run
     ntt_valu = guard("pmc_ntt_valu", measure_ntt_valu_live, a) if live is not None and a.want("ntt") else None  # third: the transform's
     try:    # PMC-measured HBM bytes per launch, recorded from a separate rocprofv3 --pmc pass
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))["acx::k_r1cs_sell"]
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))["acx::k_r1cs_sell"]
         same = tr["workload"] == {"field": a.field, "copies": a.copies, "logn": a.logn}
         if live is not None:
             if same:
